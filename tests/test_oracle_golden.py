@@ -1,0 +1,98 @@
+"""Pin the oracle: oracle/torch_ref.py and oracle/np_passport.py must reproduce what the REAL
+reference produced (tests/golden/*.npz, written by tools/gen_golden.py in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_passport as npp
+from oracle import runner
+from oracle.cases import CASES
+from tests.impls import OracleImpl, load_golden
+
+# CPU-vs-CPU, same ATen kernels: only summation-order noise is tolerated.
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def _close(a, b, name, rtol=RTOL, atol=ATOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, name
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    assert np.allclose(a, b, rtol=rtol, atol=atol * scale), '%s: max|d|=%g' % (name, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_oracle_matches_reference(name, golden_dir):
+    torch.set_num_threads(8)
+    gold = load_golden(golden_dir, name)
+    got = runner.collect(name, OracleImpl())
+    ref_keys = {k for k in gold if not k.startswith('train/acc')}
+    for k in sorted(ref_keys):
+        if k.startswith('ctor_b/'):
+            continue
+        if k.startswith('train/') and k not in got:
+            continue                         # trainer bookkeeping the oracle step does not report
+        assert k in got, k
+        if k.startswith('bits/'):
+            assert np.array_equal(got[k], gold[k]), k          # signature bits: exact
+        else:
+            _close(got[k], gold[k], k)
+
+
+def test_ctor_signature_parse(golden_dir):
+    """ASCII signature -> leading +-1 bits (passportconv2d.py:28-38)."""
+    gold = load_golden(golden_dir, 'alexnet_v1_sig')
+    cfg = CASES['alexnet_v1_sig']['config']
+    for idx in ('4', '6'):
+        text = cfg[idx]
+        ref_b = gold['ctor_b/features.' + idx]
+        mine = npp.parse_signature(text, ref_b.size, np.ones(ref_b.size))
+        n = len(text) * 8
+        assert np.array_equal(mine[:n], ref_b[:n])
+        assert set(np.unique(ref_b[n:])) <= {-1.0, 1.0}
+        assert npp.decode_signature(ref_b)[:len(text)] == text
+    with pytest.raises(Exception, match='Too much bit information'):
+        npp.parse_signature('x' * 9, 64, np.ones(64))
+    assert np.array_equal(npp.parse_signature(-1, 4, np.ones(4)), -np.ones(4))
+
+
+def test_numpy_layer_matches_reference_block(golden_dir):
+    """Layer-level: key batch 3, stride 2, no ReLU -- numpy restatement vs the reference block."""
+    gold = load_golden(golden_dir, 'blocks')
+    rs = np.random.RandomState(7)
+    w = (rs.standard_normal((16, 8, 3, 3)).astype(np.float32) * 0.2)
+    key = rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32)
+    skey = rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32)
+    x = rs.standard_normal((5, 8, 9, 9)).astype(np.float32)
+    cot = rs.standard_normal((5, 16, 5, 5)).astype(np.float32)
+    b = np.where(rs.uniform(size=16) < 0.5, -1.0, 1.0).astype(np.float32)
+    alpha = 0.5
+    W, K, SK, X, COT, B = [a.astype(np.float64) for a in (w, key, skey, x, cot, b)]
+    gamma, beta = npp.gamma_beta_fwd(W, SK, K, 2, 1)
+    xc = npp.conv2d(X, W, 2, 1)
+    y = npp.affine_relu_fwd(xc, gamma, beta, relu=False)
+    loss, acc, bits = npp.sign_loss_fwd(gamma, B, alpha)
+    _close(gamma, gold['bk3/gamma'], 'gamma')
+    _close(beta, gold['bk3/beta'], 'beta')
+    _close(y, gold['bk3/y'], 'y')
+    _close(loss, gold['bk3/sign_loss'], 'loss')
+    assert acc == pytest.approx(float(gold['bk3/sign_acc']))
+    # backward: dW gets the data conv, gamma and beta contributions (three-way)
+    dxc, dgamma, dbeta = npp.affine_relu_bwd(COT, xc, gamma, beta, relu=False)
+    dgamma = dgamma + npp.sign_loss_bwd(1.0, gamma, B, alpha)
+    dW_pass = npp.gamma_beta_bwd(dgamma, dbeta, W, SK, K, 2, 1)
+    col = npp.im2col(X, 3, 3, 2, 1)
+    dW_data = np.einsum('bol,bkl->ok', dxc.reshape(5, 16, -1), col).reshape(W.shape)
+    _close(dW_pass + dW_data, gold['bk3/dW'], 'dW', rtol=1e-4, atol=1e-5)
+    # pooled-patch identity used by the HIP kernel: gamma = W . s / n
+    s, n = npp.pooled_patch_sum(SK, 3, 3, 2, 1)
+    _close(W.reshape(16, -1) @ s / n, gold['bk3/gamma'], 'pooled gamma')
+    # d/dkey against finite differences of the forward
+    _, dsk, dk = npp.gamma_beta_bwd(dgamma, dbeta, W, SK, K, 2, 1, need_dkey=True)
+    eps = 1e-6
+    for (arr, grad, which) in ((SK, dsk, 0), (K, dk, 1)):
+        idx = (1, 3, 4, 5)
+        pert = arr.copy()
+        pert[idx] += eps
+        g2, b2 = npp.gamma_beta_fwd(W, pert if which == 0 else SK, pert if which == 1 else K, 2, 1)
+        fd = ((g2 - gamma) @ dgamma + (b2 - beta) @ dbeta) / eps
+        assert fd == pytest.approx(grad[idx], rel=1e-4, abs=1e-8)

@@ -1,0 +1,134 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (kamwoh/DeepIPR) on CPU.
+
+Build-container only: imports /root/reference (read-only), which does not exist on the GPU box.
+Only *outputs* (logits, gamma/beta, sign bits, losses, gradient digests) are written; weights and
+inputs come from oracle.patterns' name-keyed deterministic fills, so no reference source or
+pickled module ever enters this repo.
+
+    python tools/gen_golden.py            # all cases
+    python tools/gen_golden.py resnet18_v1
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('DEEPIPR_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+
+# torchvision is not installed; the reference only *calls* these for ImageNet-pretrained nets
+# (models/alexnet_passport.py:3,84-102; models/resnet_passport.py:4,123-135).
+_tv = types.ModuleType('torchvision')
+_tvm = types.ModuleType('torchvision.models')
+_tvm.alexnet = _tvm.resnet18 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError('no torchvision'))
+_tv.models = _tvm
+sys.modules.setdefault('torchvision', _tv)
+sys.modules.setdefault('torchvision.models', _tvm)
+sys.path.insert(0, REF)
+
+from experiments.trainer import Trainer                              # noqa: E402
+from experiments.trainer_private import TesterPrivate, TrainerPrivate  # noqa: E402
+from experiments.utils import construct_passport_kwargs_from_dict    # noqa: E402
+from models.alexnet_passport import AlexNetPassport                  # noqa: E402
+from models.alexnet_passport_private import AlexNetPassportPrivate   # noqa: E402
+from models.layers.passportconv2d import PassportBlock               # noqa: E402
+from models.layers.passportconv2d_private import PassportPrivateBlock  # noqa: E402
+from models.resnet_passport import ResNet18Passport                  # noqa: E402
+from models.resnet_passport_private import ResNet18Private           # noqa: E402
+
+from oracle import patterns, runner                                  # noqa: E402
+from oracle.cases import ALPHA, CASES                                # noqa: E402
+
+
+class ReferenceImpl:
+    device = torch.device('cpu')
+
+    def build(self, case):
+        kw = construct_passport_kwargs_from_dict({'passport_config': case['config'],
+                                                  'norm_type': case['norm'],
+                                                  'key_type': 'random', 'sl_ratio': ALPHA})
+        private = case['scheme'] != 1
+        if case['arch'] == 'alexnet':
+            cls = AlexNetPassportPrivate if private else AlexNetPassport
+            return cls(3, case['ncls'], kw)
+        cls = ResNet18Private if private else ResNet18Passport
+        return cls(num_classes=case['ncls'], passport_kwargs=kw)
+
+    def is_passport(self, m):
+        return isinstance(m, (PassportBlock, PassportPrivateBlock))
+
+    def is_private(self, m):
+        return isinstance(m, PassportPrivateBlock)
+
+    def step(self, model, opt, batch, wm):
+        private = any(isinstance(m, PassportPrivateBlock) for m in model.modules())
+        tr = (TrainerPrivate if private else Trainer)(model, opt, None, self.device)
+        return tr.train(0, [batch], [wm] if wm is not None else None)
+
+    def test_signature(self, model):
+        return TesterPrivate(model, self.device, verbose=False).test_signature()
+
+
+def block_cases():
+    """Layer-level vectors the model cases do not reach: key batch > 1 (mean over b,
+    passportconv2d.py:152,173), relu=False, stride 2; and passport_selection (:90-123)."""
+    out = {}
+    torch.manual_seed(0)
+    blk = PassportBlock(8, 16, 3, 2, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.5}, relu=False)
+    rs = np.random.RandomState(7)
+    w = torch.from_numpy(rs.standard_normal((16, 8, 3, 3)).astype(np.float32) * 0.2)
+    key = torch.from_numpy(rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32))
+    skey = torch.from_numpy(rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32))
+    x = torch.from_numpy(rs.standard_normal((5, 8, 9, 9)).astype(np.float32))
+    cot = torch.from_numpy(rs.standard_normal((5, 16, 5, 5)).astype(np.float32))
+    b = torch.from_numpy(np.where(rs.uniform(size=16) < 0.5, -1.0, 1.0).astype(np.float32))
+    with torch.no_grad():
+        blk.weight.copy_(w)
+        blk.b.copy_(b)
+    blk.register_buffer('key', key)          # bypass set_key's n>1 selection on purpose
+    blk.register_buffer('skey', skey)
+    x.requires_grad_(True)
+    y = blk(x)
+    total = (y * cot).sum() + blk.sign_loss.loss
+    total.backward()
+    out['bk3/y'] = y.detach().numpy()
+    out['bk3/gamma'] = blk.sign_loss.scale_cache.detach().numpy().reshape(-1)
+    out['bk3/beta'] = blk.get_bias().detach().numpy().reshape(-1)
+    out['bk3/sign_loss'] = np.float64(blk.sign_loss.loss.item())
+    out['bk3/sign_acc'] = np.float64(float(blk.sign_loss.acc))
+    out['bk3/dW'] = blk.weight.grad.numpy().copy()
+    out['bk3/dx'] = x.grad.numpy().copy()
+
+    # passport_selection is driven by python's `random` module
+    cands = torch.arange(5 * 6 * 2 * 2, dtype=torch.float32).view(5, 6, 2, 2)
+    random.seed(1234)
+    out['selection/c6'] = blk.passport_selection(cands).numpy()
+    cands3 = torch.arange(5 * 3 * 2 * 2, dtype=torch.float32).view(5, 3, 2, 2)
+    random.seed(1234)
+    out['selection/c3'] = blk.passport_selection(cands3).numpy()
+    # set_key with n>1 goes through the selection for both tensors (:128-131)
+    random.seed(99)
+    blk.set_key(cands, cands + 1000)
+    out['selection/set_key_key'] = blk.key.numpy().copy()
+    out['selection/set_key_skey'] = blk.skey.numpy().copy()
+    return out
+
+
+def main(argv):
+    names = argv or (list(CASES) + ['blocks'])
+    os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
+    torch.set_num_threads(8)
+    for name in names:
+        out = block_cases() if name == 'blocks' else runner.collect(name, ReferenceImpl())
+        path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+        np.savez_compressed(path, **{k.replace('/', '|'): v for k, v in out.items()})
+        print('%-18s %4d arrays  %7.1f KB' % (name, len(out), os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
