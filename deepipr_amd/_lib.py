@@ -1,0 +1,79 @@
+"""ctypes binding of the C-ABI kernel library (include/deepipr_hip.h).
+
+The library is the product: there is no CPU fallback.  If csrc/libdeepipr_hip.so has not been built
+(`make -C deepipr_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`), every passport
+op raises HipLibraryMissing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdeepipr_hip.so')
+
+_c = ctypes
+_f32p, _f64p, _i8p, _vp = _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p   # raw device addresses
+_int, _flt, _sz = _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/deepipr_hip.h one to one
+SIGNATURES = {
+    'deepipr_abi_version': (_int, []),
+    'deepipr_last_error': (_c.c_char_p, []),
+    'deepipr_pooled_patch_mean': (_int, [_f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f64p, _vp]),
+    'deepipr_gamma_beta_fwd': (_int, [_f32p, _f64p, _int, _int, _f32p, _f32p, _vp]),
+    'deepipr_gamma_beta_bwd': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
+    'deepipr_gamma_beta_dkey_workspace_bytes': (_sz, [_int, _int, _int]),
+    'deepipr_gamma_beta_dkey': (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int,
+                                       _f32p, _vp, _vp]),
+    'deepipr_affine_relu_fwd': (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _vp]),
+    'deepipr_affine_relu_bwd_workspace_bytes': (_sz, [_int, _int, _int]),
+    'deepipr_affine_relu_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int,
+                                       _vp, _vp]),
+    'deepipr_sign_loss_fwd': (_int, [_f32p, _f32p, _flt, _flt, _flt, _int, _f32p, _f32p, _i8p, _vp]),
+    'deepipr_sign_loss_bwd': (_int, [_f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _f32p, _vp]),
+    'deepipr_passport_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _int, _int, _int, _int, _int,
+                                    _f32p, _f32p, _f32p, _f32p, _f32p, _i8p, _vp]),
+    'deepipr_passport_bwd_workspace_bytes': (_sz, [_int, _int, _int]),
+    'deepipr_passport_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p,
+                                    _f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp, _vp]),
+}
+ABI_VERSION = 1
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (cached).  Raises HipLibraryMissing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            'deepipr_amd: %s not found. The passport layer has no CPU or PyTorch fallback; build the HIP '
+            'library first: make -C %s' % (LIB_PATH, os.path.dirname(LIB_PATH)))
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryMissing('deepipr_amd: cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise HipLibraryMissing('deepipr_amd: %s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if handle.deepipr_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing('deepipr_amd: %s has ABI version %d, expected %d' %
+                                (LIB_PATH, handle.deepipr_abi_version(), ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().deepipr_last_error()
+        raise RuntimeError('deepipr_hip.%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,144 @@
+"""Scheme-V1 train / test loops -- drop-in for the reference's experiments/trainer.py:46-214.
+
+Same constructor and return dictionaries.  What differs is how the step is driven on an MI355X:
+  * one process per GPU; a DistributedDataParallel-wrapped model (RCCL all-reduce over xGMI) is used
+    as is -- the reference's nn.DataParallel (trainer.py:92-93) is never applied;
+  * the three per-step .item() host syncs (trainer.py:147-149) are replaced by on-device meters that
+    are read once per epoch (or every `log_interval` batches when progress printing is wanted).
+"""
+import time
+
+import torch
+import torch.nn.functional as F
+
+from deepipr_amd.models.losses.sign_loss import SignLoss
+
+
+def accuracy(output, target, topk=(1,)):
+    """precision@k in percent (trainer.py:28-43)."""
+    with torch.no_grad():
+        maxk = max(topk)
+        _, pred = output.topk(maxk, 1, True, True)
+        correct = pred.t().eq(target.view(1, -1))
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+def sign_loss_modules(model):
+    return [m for m in model.modules() if isinstance(m, SignLoss)]
+
+
+def reset_sign_losses(model):
+    for m in sign_loss_modules(model):
+        m.reset()
+
+
+def total_sign_loss(model, device):
+    total = torch.zeros((), device=device)
+    for m in sign_loss_modules(model):
+        total = total + m.loss
+    return total
+
+
+def mean_sign_acc(model, device):
+    """Mean over SignLoss modules of the accuracy of the LAST forward (the meters are reset every step,
+    trainer.py:131-133,162-171)."""
+    mods = sign_loss_modules(model)
+    acc = torch.zeros((), device=device)
+    for m in mods:
+        acc = acc + m.acc
+    return acc / len(mods) if mods else acc
+
+
+def next_trigger_batch(state, wm_dataloader):
+    """Cycle through the trigger-set loader (trainer.py:115-120)."""
+    try:
+        return next(state['it'])
+    except StopIteration:
+        state['it'] = iter(wm_dataloader)
+        return next(state['it'])
+
+
+def train_step_v1(model, optimizer, data, target):
+    """One batch: zero_grad, reset sign losses, forward, CE + sum of sign losses, backward, SGD step
+    (trainer.py:128-145).  Returns device scalars (loss, sign_loss, top-1 %), no host sync."""
+    optimizer.zero_grad(set_to_none=True)
+    reset_sign_losses(model)
+    pred = model(data)
+    loss = F.cross_entropy(pred, target)
+    sign_loss = total_sign_loss(model, data.device)
+    (loss + sign_loss).backward()
+    optimizer.step()
+    return loss.detach(), sign_loss.detach(), accuracy(pred, target)[0][0]
+
+
+class Tester(object):
+    def __init__(self, model, device, verbose=True):
+        self.model = model
+        self.device = device
+        self.verbose = verbose
+
+    def test(self, dataloader, msg='Testing Result', compare=[]):
+        self.model.eval()
+        start = time.time()
+        loss_sum = torch.zeros((), device=self.device)
+        correct = torch.zeros((), device=self.device)
+        count = 0
+        with torch.no_grad():
+            for load in dataloader:
+                data = load[0].to(self.device, non_blocking=True)
+                target = load[1].to(self.device, non_blocking=True)
+                pred = self.model(data)
+                loss_sum += F.cross_entropy(pred, target, reduction='sum')
+                top = pred.max(1, keepdim=True)[1]
+                compare.append((top, target))
+                correct += top.eq(target.view_as(top)).sum()
+                count += data.size(0)
+        loss = loss_sum.item() / count
+        acc = 100 * correct.item() / count
+        if self.verbose:
+            print(f'{msg}: Loss: {loss:6.4f} Acc: {acc:6.2f} ({time.time() - start:.2f}s)')
+            print()
+        return {'loss': loss, 'acc': acc, 'time': time.time() - start}
+
+
+class Trainer(object):
+    def __init__(self, model, optimizer, scheduler, device, log_interval=0):
+        self.model = model
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.device = device
+        self.log_interval = log_interval
+
+    def train(self, e, dataloader, wm_dataloader=None):
+        self.model.train()
+        dev = self.device
+        meters = torch.zeros(3, device=dev)                     # sign loss, loss, acc
+        wm_state = {'it': iter(wm_dataloader)} if wm_dataloader is not None else None
+        start = time.time()
+        for i, (data, target) in enumerate(dataloader):
+            data = data.to(dev, non_blocking=True)
+            target = target.to(dev, non_blocking=True)
+            if wm_state is not None:                            # V1 + backdoor: append the trigger pair
+                wm_data, wm_target = next_trigger_batch(wm_state, wm_dataloader)
+                data = torch.cat([data, wm_data.to(dev, non_blocking=True)], dim=0)
+                target = torch.cat([target, wm_target.to(dev, non_blocking=True)], dim=0)
+            loss, sign_loss, acc = train_step_v1(self.model, self.optimizer, data, target)
+            meters += torch.stack([sign_loss, loss, acc])
+            if self.log_interval and (i + 1) % self.log_interval == 0:
+                s, l, a = (meters / (i + 1)).tolist()
+                print(f'Epoch {e:3d} [{i:4d}/{len(dataloader):4d}] Sign Loss: {s:6.4f} Loss: {l:6.4f} '
+                      f'Acc: {a:.4f} ({time.time() - start:.2f}s)', end='\r')
+        if self.log_interval:
+            print()
+        n = max(1, len(dataloader))
+        sign_acc = mean_sign_acc(self.model, dev)
+        s, l, a, sa = torch.cat([meters / n, sign_acc.reshape(1)]).tolist()     # the epoch's only host sync
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return {'loss': l, 'sign_loss': s, 'sign_acc': sa, 'acc': a, 'time': time.time() - start}
+
+    def test(self, dataloader, msg='Testing Result'):
+        out = Tester(self.model, self.device, verbose=False).test(dataloader, msg, compare=[])
+        print(f'{msg}: Loss: {out["loss"]:6.4f} Acc: {out["acc"]:6.2f} ({out["time"]:.2f}s)')
+        print()
+        return out

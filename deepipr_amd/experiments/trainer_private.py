@@ -1,0 +1,164 @@
+"""Scheme V2 / V3 train / test loops and signature detection -- drop-in for the reference's
+experiments/trainer_private.py:29-257.
+
+A step is two forwards (ind=0 public, ind=1 private) whose cross-entropies are summed, plus the private
+sign losses, and ONE backward (trainer_private.py:159-173).  Under DistributedDataParallel the two
+forwards are issued through `DualBranch`, so the wrapper sees a single forward per backward.
+"""
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from deepipr_amd.experiments.trainer import (accuracy, mean_sign_acc, next_trigger_batch, reset_sign_losses,
+                                             total_sign_loss)
+from deepipr_amd.models.layers.passportconv2d import PassportBlock
+from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
+
+
+class DualBranch(nn.Module):
+    """model(x, ind=0) and model(x, ind=1) in one forward call, public branch first so that the batch-norm
+    running statistics are updated in the reference's order."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, data):
+        return self.model(data, ind=0), self.model(data, ind=1)
+
+
+def _unwrap(model):
+    while hasattr(model, 'module'):
+        model = model.module
+    return model.model if isinstance(model, DualBranch) else model
+
+
+def train_step_v23(dual, optimizer, data, target):
+    """-> device scalars (loss, sign_loss, public top-1 %, private top-1 %)."""
+    optimizer.zero_grad(set_to_none=True)
+    reset_sign_losses(dual)
+    pred_public, pred_private = dual(data)
+    loss = F.cross_entropy(pred_public, target) + F.cross_entropy(pred_private, target)
+    sign_loss = total_sign_loss(dual, data.device)
+    (loss + sign_loss).backward()
+    optimizer.step()
+    return (loss.detach(), sign_loss.detach(), accuracy(pred_public, target)[0][0],
+            accuracy(pred_private, target)[0][0])
+
+
+class TesterPrivate(object):
+    def __init__(self, model, device, verbose=True):
+        self.model = model
+        self.device = device
+        self.verbose = verbose
+
+    def test_signature(self):
+        """sign(gamma) == b per passport layer (trainer_private.py:37-71): 'private_<name>' for
+        PassportPrivateBlock (gamma of the private branch), 'public_<name>' for PassportBlock."""
+        model = _unwrap(self.model)
+        model.eval()
+        names, rates = [], []
+        with torch.no_grad():
+            for name, m in model.named_modules():
+                if isinstance(m, PassportPrivateBlock):
+                    bits = m.get_scale(ind=1).view(-1).sign()
+                    names.append('private_' + name)
+                elif isinstance(m, PassportBlock):
+                    bits = m.get_scale().view(-1).sign()
+                    names.append('public_' + name)
+                else:
+                    continue
+                rates.append((bits == m.b).float().mean())
+        values = torch.stack(rates).tolist() if rates else []
+        res = dict(zip(names, values))
+        for kind in ('private', 'public'):
+            sel = [v for k, v in res.items() if k.startswith(kind + '_')]
+            if sel and self.verbose:
+                print(f'{kind.capitalize()} Sign Detection Accuracy: {sum(sel) / len(sel) * 100:6.4f}')
+        return res
+
+    def test(self, dataloader, msg='Testing Result', ind=0):
+        model = _unwrap(self.model)
+        model.eval()
+        start = time.time()
+        loss_sum = torch.zeros((), device=self.device)
+        correct = torch.zeros((), device=self.device)
+        count = 0
+        with torch.no_grad():
+            for load in dataloader:
+                data = load[0].to(self.device, non_blocking=True)
+                target = load[1].to(self.device, non_blocking=True)
+                pred = model(data, ind=ind)
+                loss_sum += F.cross_entropy(pred, target, reduction='sum')
+                top = pred.max(1, keepdim=True)[1]
+                correct += top.eq(target.view_as(top)).sum()
+                count += data.size(0)
+        loss = loss_sum.item() / count
+        acc = 100 * correct.item() / count
+        if self.verbose:
+            print(f'{msg}: Loss: {loss:6.4f} Acc: {acc:6.2f} ({time.time() - start:.2f}s)')
+            print()
+        return {'loss': loss, 'acc': acc, 'time': time.time() - start}
+
+
+class TrainerPrivate(object):
+    def __init__(self, model, optimizer, scheduler, device, log_interval=0):
+        self.model = model
+        self.dual = model if isinstance(_strip_ddp(model), DualBranch) else DualBranch(model)
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.device = device
+        self.log_interval = log_interval
+        self.tester = TesterPrivate(model, device)
+
+    def train(self, e, dataloader, wm_dataloader=None):
+        self.dual.train()
+        dev = self.device
+        meters = torch.zeros(4, device=dev)                     # loss, sign loss, public acc, private acc
+        wm_state = {'it': iter(wm_dataloader)} if wm_dataloader is not None else None
+        start = time.time()
+        for i, (data, target) in enumerate(dataloader):
+            data = data.to(dev, non_blocking=True)
+            target = target.to(dev, non_blocking=True)
+            if wm_state is not None:                            # V3: trigger-set pair appended to the batch
+                wm_data, wm_target = next_trigger_batch(wm_state, wm_dataloader)
+                data = torch.cat([data, wm_data.to(dev, non_blocking=True)], dim=0)
+                target = torch.cat([target, wm_target.to(dev, non_blocking=True)], dim=0)
+            meters += torch.stack(train_step_v23(self.dual, self.optimizer, data, target))
+            if self.log_interval and (i + 1) % self.log_interval == 0:
+                l, s, pu, pr = (meters / (i + 1)).tolist()
+                print(f'Epoch {e:3d} [{i:4d}/{len(dataloader):4d}] Loss: {l:6.4f} Sign Loss: {s:6.4f} '
+                      f'Priv. Acc: {pr:.4f} Publ. Acc: {pu:.4f} ({time.time() - start:.2f}s)', end='\r')
+        if self.log_interval:
+            print()
+        n = max(1, len(dataloader))
+        sign_acc = mean_sign_acc(self.dual, dev)
+        raw = torch.cat([meters, sign_acc.reshape(1)]).tolist()                  # the epoch's only host sync
+        if self.scheduler is not None:
+            self.scheduler.step()
+        # the reference divides every meter by len(dataloader) except sign_loss (trainer_private.py:189-191)
+        return {'loss': raw[0] / n, 'sign_loss': raw[1], 'sign_acc': raw[4],
+                'acc_public': raw[2] / n, 'acc_private': raw[3] / n, 'time': time.time() - start}
+
+    def test(self, dataloader, msg='Testing Result'):
+        out = {}
+        quiet = TesterPrivate(self.model, self.device, verbose=False)
+        for i, key in enumerate(('public', 'private')):
+            r = quiet.test(dataloader, msg, ind=i)
+            print(f'{msg} {key}: Loss: {r["loss"]:6.4f} Acc: {r["acc"]:6.2f} ({r["time"]:.2f}s)')
+            print()
+            out.update({'loss_' + key: r['loss'], 'acc_' + key: r['acc'], 'time_' + key: r['time']})
+        out['total_acc'] = (out['acc_public'] + out['acc_private']) / 2
+        print(f'Total acc: {out["total_acc"]:.2f}')
+        print()
+        for key, val in self.tester.test_signature().items():
+            out['s_' + key] = val
+        return out
+
+
+def _strip_ddp(model):
+    while hasattr(model, 'module'):
+        model = model.module
+    return model

@@ -1,0 +1,60 @@
+"""AlexNet with per-layer passport flags -- drop-in for the reference's models/alexnet_passport.py:9-122
+(V1) and, via `passport_cls`, models/alexnet_passport_private.py:9-121 (V2/V3).
+
+CIFAR geometry (num_classes != 1000): 5x5 stem, 2x2 max-pools after features 0, 2 and 6, a single
+Linear(4*4*256, num_classes); ImageNet geometry: 11x11/4 stem, 3x3/2 pools, adaptive 6x6 pool and the
+three-layer dropout classifier.  `features` indices 0,2,4,5,6 are the conv layers, as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer
+from deepipr_amd.models.layers.passportconv2d import PassportBlock
+
+_WIDTHS = {0: 64, 2: 192, 4: 384, 5: 256, 6: 256}
+_POOL_AT = (1, 3, 7)
+
+
+class AlexNetPassport(nn.Module):
+    passport_cls = PassportBlock
+
+    def __init__(self, in_channels, num_classes, passport_kwargs, pretrained=False, imagenet=False):
+        super().__init__()
+        big = num_classes == 1000
+        if pretrained and big:
+            raise NotImplementedError('torchvision-pretrained ImageNet weights are not available offline; '
+                                      'load a state_dict instead')
+        geometry = {0: (11, 4, 2) if big else (5, 1, 2), 2: (5, 1, 2), 4: (3, 1, 1), 5: (3, 1, 1), 6: (3, 1, 1)}
+        layers, inp = [], in_channels
+        for idx in range(8):
+            if idx in _POOL_AT:
+                layers.append(nn.MaxPool2d(3 if big else 2, 2))
+                continue
+            k, s, p = geometry[idx]
+            layers.append(conv_factory(passport_kwargs[str(idx)], self.passport_cls)(inp, _WIDTHS[idx], k, s, p))
+            inp = _WIDTHS[idx]
+        if big or imagenet:
+            layers.append(nn.AdaptiveAvgPool2d((6, 6)))
+        self.features = nn.Sequential(*layers)
+        if big or imagenet:
+            self.classifier = nn.Sequential(
+                nn.Dropout(), nn.Linear(256 * 6 * 6, 4096), nn.ReLU(inplace=True),
+                nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
+                nn.Linear(4096, num_classes))
+        else:
+            self.classifier = nn.Linear(4 * 4 * 256, num_classes)
+
+    def set_intermediate_keys(self, pretrained_model, x, y=None):
+        """models/alexnet_passport.py:104-112."""
+        with torch.no_grad():
+            for theirs, mine in zip(pretrained_model.features, self.features):
+                if isinstance(mine, PASSPORT_TYPES):
+                    mine.set_key(x, y)
+                x = theirs(x)
+                if y is not None:
+                    y = theirs(y)
+
+    def forward(self, x, force_passport=False, ind=0):
+        for m in self.features:
+            x = run_layer(m, x, force_passport, ind)
+        return self.classifier(x.view(x.size(0), -1))

@@ -1,0 +1,208 @@
+"""Shared machinery of PassportBlock (V1) and PassportPrivateBlock (V2/V3).
+
+The reference keeps two near-identical 220-line classes (models/layers/passportconv2d.py,
+models/layers/passportconv2d_private.py); here the behaviour lives once and the two public classes
+only choose buffer names and defaults.  Data conv and norm stay on MIOpen; everything after the norm
+(passport conv -> pool -> gamma/beta, sign loss, affine, ReLU and all of their backward) goes through
+deepipr_amd.passport_ops, i.e. the HIP kernels.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from deepipr_amd import passport_ops as P
+from deepipr_amd.models.layers.conv2d import make_norm
+from deepipr_amd.models.losses.sign_loss import SignLoss
+
+
+def signature_vector(spec, channels, random_sign):
+    """passport_kwargs['b'] -> +-1 per output channel (passportconv2d.py:25-40).
+
+    int -> constant vector; str -> 8 bits per character, most significant first ('0' -> -1), written over
+    the leading channels of a fresh random-sign vector; more than `channels` bits is an error."""
+    if isinstance(spec, int):
+        return torch.ones(channels) * spec
+    if isinstance(spec, str):
+        if len(spec) * 8 > channels:
+            raise Exception('Too much bit information')
+        vec = random_sign()
+        bits = ''.join(format(ord(ch), 'b').zfill(8) for ch in spec)
+        vec[:len(bits)] = torch.tensor([1.0 if ch == '1' else -1.0 for ch in bits])
+        return vec
+    return spec
+
+
+class PassportLayerBase(nn.Module):
+    # subclasses set these
+    KEY = 'key'
+    SKEY = 'skey'
+    SIGN = 'sign_loss'
+
+    def _build(self, i, o, ks, s, pd, passport_kwargs, relu, learnable_affine, always_sign_loss):
+        if passport_kwargs == {}:
+            print('Warning, passport_kwargs is empty')
+        # RNG draw order below equals the reference's constructor, so the same torch seed gives the
+        # same initial weights and signature bits (passportconv2d.py:18,25,31,88).
+        self.conv = nn.Conv2d(i, o, ks, s, pd, bias=False)
+        self.key_type = passport_kwargs.get('key_type', 'random')
+        self.weight = self.conv.weight
+        self.alpha = passport_kwargs.get('sign_loss', 1)
+
+        def random_sign():
+            return torch.sign(torch.rand(o) - 0.5)
+        b = signature_vector(passport_kwargs.get('b', random_sign()), o, random_sign)
+        self.register_buffer('b', b)
+        self.requires_reset_key = False
+        if always_sign_loss or self.alpha != 0:
+            setattr(self, self.SIGN, SignLoss(self.alpha, self.b))
+        else:
+            setattr(self, self.SIGN, None)
+        self.register_buffer(self.KEY, None)
+        self.register_buffer(self.SKEY, None)
+        self.init_scale(learnable_affine)
+        self.init_bias(learnable_affine)
+        norm = make_norm(passport_kwargs.get('norm_type', 'bn'), o, affine=False)
+        self.bn = norm if norm is not None else nn.Sequential()
+        self.relu = nn.ReLU(inplace=True) if relu else None
+        self._pooled = P.PooledKeys()
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def init_bias(self, force_init=False):
+        if force_init:
+            self.bias = nn.Parameter(torch.zeros(self.conv.out_channels, device=self.weight.device))
+        else:
+            self.bias = None
+
+    def init_scale(self, force_init=False):
+        if force_init:
+            self.scale = nn.Parameter(torch.ones(self.conv.out_channels, device=self.weight.device))
+        else:
+            self.scale = None
+
+    def reset_parameters(self):
+        nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+
+    # ------------------------------------------------------------------ keys
+    def passport_selection(self, passport_candidates):
+        """n candidate activations -> one [1,C,H,W] passport (passportconv2d.py:90-123): for RGB inputs
+        one whole image; otherwise channel j comes from candidate j mod n, a not-yet-used channel of it
+        drawn with python's `random` (same draw sequence as the reference)."""
+        n, c, h, w = passport_candidates.size()
+        if c == 3:
+            return passport_candidates[random.randint(0, n - 1)].unsqueeze(0)
+        flat = passport_candidates.view(n * c, h, w)
+        used, picks = set(), []
+        for j in range(c):
+            base = (j % n) * c
+            pick = base + random.randint(0, c - 1)
+            while pick in used:
+                pick = base + random.randint(0, c - 1)
+            used.add(pick)
+            picks.append(pick)
+        return flat[picks].unsqueeze(0)
+
+    def set_key(self, x, y=None):
+        """x -> bias key, y -> scale key (passportconv2d.py:125-137)."""
+        if int(x.size(0)) != 1:
+            x = self.passport_selection(x)
+            if y is not None:
+                y = self.passport_selection(y)
+        self.register_buffer(self.KEY, x)
+        self.register_buffer(self.SKEY, y)
+
+    def generate_key(self, *shape):
+        shape = [1] + list(shape[1:])
+        return np.random.uniform(-1.0, 1.0, shape)
+
+    def get_scale_key(self):
+        return getattr(self, self.SKEY)
+
+    def get_bias_key(self):
+        return getattr(self, self.KEY)
+
+    def _sign(self):
+        return getattr(self, self.SIGN)
+
+    def _geometry(self):
+        c = self.conv
+        if c.groups != 1 or tuple(c.dilation) != (1, 1) or c.stride[0] != c.stride[1] or c.padding[0] != c.padding[1]:
+            raise RuntimeError('passport conv must be a plain square-stride, square-padding convolution')
+        return c.kernel_size[0], c.kernel_size[1], c.stride[0], c.padding[0]
+
+    def _pooled_means(self):
+        skey, key = self.get_scale_key(), self.get_bias_key()
+        if skey is None or key is None:
+            raise RuntimeError('passport keys are not set (call set_key, or use key_type="random")')
+        kh, kw, stride, pad = self._geometry()
+        return skey, key, self._pooled.get(skey, key, kh, kw, stride, pad), stride, pad
+
+    # ------------------------------------------------------------------ gamma / beta
+    def _use_param(self, param, force_passport, ind):
+        return param is not None and not force_passport and ind == 0
+
+    def _passport_gamma_beta(self):
+        skey, key, m, stride, pad = self._pooled_means()
+        return P.gamma_beta(self.weight, skey, key, m, stride, pad)
+
+    def get_scale(self, force_passport=False, ind=0):
+        """[1,C,1,1] gamma: the learnable `scale` on the public branch, otherwise the pooled response of
+        the layer's own conv to the scale key, which also (re)sets the sign loss
+        (passportconv2d.py:142-158; private :139-156)."""
+        if self._use_param(self.scale, force_passport, ind):
+            return self.scale.view(1, -1, 1, 1)
+        gamma = self._passport_gamma_beta()[0].view(1, -1, 1, 1)
+        sl = self._sign()
+        if sl is not None:
+            sl.reset()
+            sl.add(gamma)
+        return gamma
+
+    def get_bias(self, force_passport=False, ind=0):
+        """[1,C,1,1] beta (passportconv2d.py:163-175; private :161-173)."""
+        if self._use_param(self.bias, force_passport, ind):
+            return self.bias.view(1, -1, 1, 1)
+        return self._passport_gamma_beta()[1].view(1, -1, 1, 1)
+
+    # ------------------------------------------------------------------ checkpoints
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """Pre-size the lazily created tensors so strict loads of reference checkpoints succeed
+        (passportconv2d.py:177-196)."""
+        dev = self.weight.device
+        for name in (self.KEY, self.SKEY):
+            if prefix + name in state_dict:
+                self.register_buffer(name, torch.empty(state_dict[prefix + name].size(), device=dev))
+        for name in ('scale', 'bias'):
+            if prefix + name in state_dict:
+                setattr(self, name, nn.Parameter(torch.empty(state_dict[prefix + name].size(), device=dev)))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, x, force_passport, ind):
+        if (self.get_bias_key() is None and self.key_type == 'random') or self.requires_reset_key:
+            self.set_key(torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device),
+                         torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device))
+        x = self.conv(x)
+        x = self.bn(x)
+        relu = self.relu is not None
+        p_scale = self._use_param(self.scale, force_passport, ind)
+        p_bias = self._use_param(self.bias, force_passport, ind)
+        if p_scale and p_bias:                       # public branch: learnable affine, no sign loss
+            return P.affine_relu(x, self.scale, self.bias, relu)
+        sl = self._sign()
+        if not p_scale and not p_bias:               # passport branch: the fused two-launch layer
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_layer(
+                x, self.weight, skey, key, self.b if sl is not None else None, m, self.alpha, relu, stride, pad)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
+        # mixed (only one of scale / bias learnable): compose the unfused operators
+        gamma = self.get_scale(force_passport, ind)
+        beta = self.get_bias(force_passport, ind)
+        return P.affine_relu(x, gamma, beta, relu)

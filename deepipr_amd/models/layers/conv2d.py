@@ -1,0 +1,36 @@
+"""ConvBlock: conv -> norm(affine) -> ReLU for the un-passported layers (reference
+models/layers/conv2d.py:5-36).  These stay on the vendor library (MIOpen conv / batch-norm), as the
+north star prescribes; only the passport layers get hand-written kernels."""
+import torch.nn as nn
+
+
+def make_norm(norm_type, channels, affine):
+    """'bn' | 'gn' (channels // 16 groups) | 'in' | anything else -> no norm.
+    models/layers/conv2d.py:15-22 and models/layers/passportconv2d.py:56-64."""
+    if norm_type == 'bn':
+        return nn.BatchNorm2d(channels, affine=affine)
+    if norm_type == 'gn':
+        return nn.GroupNorm(channels // 16, channels, affine=affine)
+    if norm_type == 'in':
+        return nn.InstanceNorm2d(channels)          # the reference never makes this one affine
+    return None
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, i, o, ks=3, s=1, pd=1, bn='bn', relu=True):
+        super().__init__()
+        self.conv = nn.Conv2d(i, o, ks, s, pd, bias=(bn == 'none'))
+        self.bn = make_norm(bn, o, affine=True)
+        self.relu = nn.ReLU(inplace=True) if relu else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.relu is not None:
+            x = self.relu(x)
+        return x

@@ -1,0 +1,327 @@
+"""Passport-layer operators: torch autograd Functions over the HIP C ABI (include/deepipr_hip.h).
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); the arithmetic of the
+passport layer runs in csrc/deepipr_hip.hip.  There is no CPU / eager fallback: a tensor that is not a
+dense fp32 tensor on an AMD GPU raises, and so does a missing library (deepipr_amd._lib).
+
+Reference lines each operator stands in for (paths relative to kamwoh/DeepIPR):
+  gamma_beta          models/layers/passportconv2d.py:142-175  (get_scale / get_bias, passport branch)
+  affine_relu         models/layers/passportconv2d.py:220-222
+  sign_loss           models/losses/sign_loss.py:18-54
+  passport_layer      all of the above in two launches forward, two backward
+"""
+import torch
+
+from deepipr_amd import _lib
+
+MARGIN = 0.1      # models/losses/sign_loss.py:27
+L2 = 0.00001      # models/losses/sign_loss.py:53
+
+
+def _chk(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('deepipr_amd passport ops run on the GPU only (got a %s tensor); there is no '
+                               'CPU fallback' % t.device)
+        if t.dtype not in (torch.float32, torch.float64, torch.int8):
+            raise RuntimeError('deepipr_amd passport ops are fp32-only (got %s)' % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError('deepipr_amd passport ops need dense contiguous tensors')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('deepipr_amd passport ops: tensors on different devices (%s, %s)' % (dev, t.device))
+    return dev
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """One method per C-ABI entry point; tensors in, freshly allocated tensors out."""
+
+    def pooled_patch_mean(self, keys, kh, kw, stride, pad):
+        # keys [nkeys, B, Ci, H, W] -> m [nkeys, Ci*kh*kw] float64
+        dev = _chk(keys)
+        nk, b, ci, h, w = keys.shape
+        m = torch.empty((nk, ci * kh * kw), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_pooled_patch_mean(_p(keys), nk, b, ci, h, w, kh, kw, stride, pad, _p(m),
+                                                           _stream(dev)), 'pooled_patch_mean')
+        return m
+
+    def gamma_beta_fwd(self, weight, m):
+        dev = _chk(weight, m)
+        co = weight.shape[0]
+        k = weight.numel() // co
+        gb = torch.empty((2, co), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_gamma_beta_fwd(_p(weight), _p(m), co, k, _p(gb[0]), _p(gb[1]),
+                                                        _stream(dev)), 'gamma_beta_fwd')
+        return gb[0], gb[1]
+
+    def gamma_beta_bwd(self, dgamma, dbeta, m, wshape):
+        dev = _chk(dgamma, dbeta, m)
+        co = wshape[0]
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_gamma_beta_bwd(_p(dgamma), _p(dbeta), _p(m), co, dw.numel() // co, _p(dw),
+                                                        _stream(dev)), 'gamma_beta_bwd')
+        return dw
+
+    def gamma_beta_dkey(self, dgamma, dbeta, weight, key_shape, stride, pad):
+        dev = _chk(dgamma, dbeta, weight)
+        co, ci, kh, kw = weight.shape
+        b, _, h, w = key_shape
+        lib = _lib.lib()
+        ws = torch.empty(lib.deepipr_gamma_beta_dkey_workspace_bytes(ci, kh, kw), dtype=torch.uint8, device=dev)
+        dkeys = torch.empty((2, b, ci, h, w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.deepipr_gamma_beta_dkey(_p(dgamma), _p(dbeta), _p(weight), co, b, ci, h, w, kh, kw,
+                                                  stride, pad, _p(dkeys), _p(ws), _stream(dev)), 'gamma_beta_dkey')
+        return dkeys[0], dkeys[1]
+
+    def affine_relu_fwd(self, xhat, gamma, beta, relu):
+        dev = _chk(xhat, gamma, beta)
+        n, c = xhat.shape[0], xhat.shape[1]
+        y = torch.empty_like(xhat)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_affine_relu_fwd(_p(xhat), _p(gamma), _p(beta), _p(y), n, c,
+                                                         xhat.numel() // (n * c), int(relu), _stream(dev)),
+                       'affine_relu_fwd')
+        return y
+
+    def affine_relu_bwd(self, dy, xhat, gamma, beta, relu):
+        dev = _chk(dy, xhat, gamma, beta)
+        n, c = xhat.shape[0], xhat.shape[1]
+        hw = xhat.numel() // (n * c)
+        lib = _lib.lib()
+        ws = torch.empty(lib.deepipr_affine_relu_bwd_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(xhat)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.deepipr_affine_relu_bwd(_p(dy), _p(xhat), _p(gamma), _p(beta), _p(dx), _p(dgb[0]),
+                                                  _p(dgb[1]), n, c, hw, int(relu), _p(ws), _stream(dev)),
+                       'affine_relu_bwd')
+        return dx, dgb[0], dgb[1]
+
+    def sign_loss_fwd(self, gamma, b, alpha, margin=MARGIN, l2=L2):
+        dev = _chk(gamma, b)
+        c = gamma.numel()
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        bits = torch.empty(c, dtype=torch.int8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_sign_loss_fwd(_p(gamma), _p(b), alpha, margin, l2, c, _p(out[0]),
+                                                       _p(out[1]), _p(bits), _stream(dev)), 'sign_loss_fwd')
+        return out[0], out[1], bits
+
+    def sign_loss_bwd(self, dloss, gamma, b, alpha, margin=MARGIN, l2=L2):
+        dev = _chk(dloss, gamma, b)
+        dg = torch.empty_like(gamma)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_sign_loss_bwd(_p(dloss), _p(gamma), _p(b), alpha, margin, l2,
+                                                       gamma.numel(), _p(dg), _stream(dev)), 'sign_loss_bwd')
+        return dg
+
+    def passport_fwd(self, xhat, weight, m, b, alpha, relu, margin=MARGIN, l2=L2):
+        """-> y, gamma, beta, loss, acc, bits (the last three None when b is None)."""
+        dev = _chk(xhat, weight, m, b)
+        n, c = xhat.shape[0], xhat.shape[1]
+        hw = xhat.numel() // (n * c)
+        k = weight.numel() // c
+        y = torch.empty_like(xhat)
+        gb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        sl = bits = None
+        if b is not None:
+            sl = torch.empty(2, dtype=torch.float32, device=dev)
+            bits = torch.empty(c, dtype=torch.int8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().deepipr_passport_fwd(
+                _p(xhat), _p(weight), _p(m), _p(b), alpha, margin, l2, n, c, hw, k, int(relu), _p(y), _p(gb[0]),
+                _p(gb[1]), _p(sl[0]) if sl is not None else None, _p(sl[1]) if sl is not None else None, _p(bits),
+                _stream(dev)), 'passport_fwd')
+        if sl is None:
+            return y, gb[0], gb[1], None, None, None
+        return y, gb[0], gb[1], sl[0], sl[1], bits
+
+    def passport_bwd(self, dy, xhat, gamma, beta, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu,
+                     margin=MARGIN, l2=L2):
+        """-> dxhat, dW, dgamma, dbeta."""
+        dev = _chk(dy, xhat, gamma, beta, m, b, dloss, dgamma_extra, dbeta_extra)
+        n, c = xhat.shape[0], xhat.shape[1]
+        hw = xhat.numel() // (n * c)
+        lib = _lib.lib()
+        ws = torch.empty(lib.deepipr_passport_bwd_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(xhat)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.deepipr_passport_bwd(
+                _p(dy), _p(xhat), _p(gamma), _p(beta), _p(m), _p(b), alpha, margin, l2, _p(dloss),
+                _p(dgamma_extra), _p(dbeta_extra), n, c, hw, dw.numel() // c, int(relu), _p(dx), _p(dw),
+                _p(dgb[0]), _p(dgb[1]), _p(ws), _stream(dev)), 'passport_bwd')
+        return dx, dw, dgb[0], dgb[1]
+
+
+kernels = HipKernels()
+
+
+# ---------------------------------------------------------------------------------------------
+# pooled passport patches, cached per key version (keys are constant buffers while training)
+# ---------------------------------------------------------------------------------------------
+class PooledKeys:
+    """Caches m = pooled_patch_mean([skey, key]) for one layer.  The cache key is the storage address
+    and in-place version counter of both tensors, so set_key / load_state_dict / an optimiser step on
+    trainable keys (passport_attack_3.py:232-243) all invalidate it."""
+
+    def __init__(self):
+        self._sig = None
+        self._m = None
+
+    def get(self, skey, key, kh, kw, stride, pad):
+        if skey.shape != key.shape:
+            raise RuntimeError('passport scale key %s and bias key %s must have the same shape'
+                               % (tuple(skey.shape), tuple(key.shape)))
+        sig = (skey.data_ptr(), skey._version, key.data_ptr(), key._version, tuple(key.shape), key.device,
+               kh, kw, stride, pad)
+        if sig != self._sig:
+            with torch.no_grad():
+                both = torch.stack([skey.detach(), key.detach()]).to(torch.float32).contiguous()
+                self._m = kernels.pooled_patch_mean(both, kh, kw, stride, pad)
+            self._sig = sig
+        return self._m
+
+    def clear(self):
+        self._sig = self._m = None
+
+
+def _grad_or_none(g):
+    return None if g is None else g.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------------
+class _AffineReLU(torch.autograd.Function):
+    """y = relu?(gamma*xhat + beta) with free-standing gamma/beta (learnable scale/bias of the public
+    branch, models/layers/passportconv2d_private.py:140-141,162-163)."""
+
+    @staticmethod
+    def forward(ctx, xhat, gamma, beta, relu):
+        xhat, gamma, beta = xhat.contiguous(), gamma.contiguous(), beta.contiguous()
+        y = kernels.affine_relu_fwd(xhat, gamma, beta, relu)
+        ctx.save_for_backward(xhat, gamma, beta)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, gamma, beta = ctx.saved_tensors
+        dx, dg, db = kernels.affine_relu_bwd(dy.contiguous(), xhat, gamma, beta, ctx.relu)
+        return dx, dg, db, None
+
+
+class _GammaBeta(torch.autograd.Function):
+    """(gamma, beta) = pooled passport conv of (skey, key) with the layer's own weight."""
+
+    @staticmethod
+    def forward(ctx, weight, skey, key, m, stride, pad):
+        weight = weight.contiguous()
+        gamma, beta = kernels.gamma_beta_fwd(weight, m)
+        ctx.save_for_backward(weight, m)
+        ctx.geom = (tuple(key.shape), stride, pad)
+        return gamma, beta
+
+    @staticmethod
+    def backward(ctx, dgamma, dbeta):
+        weight, m = ctx.saved_tensors
+        key_shape, stride, pad = ctx.geom
+        zeros = None
+        if dgamma is None or dbeta is None:
+            zeros = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device)
+        dgamma = zeros if dgamma is None else dgamma.contiguous()
+        dbeta = zeros if dbeta is None else dbeta.contiguous()
+        dw = kernels.gamma_beta_bwd(dgamma, dbeta, m, weight.shape) if ctx.needs_input_grad[0] else None
+        dsk = dk = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dsk, dk = kernels.gamma_beta_dkey(dgamma, dbeta, weight, key_shape, stride, pad)
+        return dw, dsk if ctx.needs_input_grad[1] else None, dk if ctx.needs_input_grad[2] else None, None, None, None
+
+
+class _SignLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gamma, b, alpha, l2):
+        gamma, b = gamma.contiguous().view(-1), b.contiguous().view(-1)
+        loss, acc, bits = kernels.sign_loss_fwd(gamma, b, float(alpha), MARGIN, float(l2))
+        ctx.save_for_backward(gamma, b)
+        ctx.cfg = (float(alpha), float(l2))
+        ctx.mark_non_differentiable(acc, bits)
+        return loss, acc, bits
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc, _dbits):
+        gamma, b = ctx.saved_tensors
+        alpha, l2 = ctx.cfg
+        return kernels.sign_loss_bwd(dloss.contiguous(), gamma, b, alpha, MARGIN, l2), None, None, None
+
+
+class _PassportLayer(torch.autograd.Function):
+    """The fused passport layer after the norm: two launches forward, two backward.
+
+    inputs : xhat, weight, skey, key, b (or None), m (pooled means, no grad)
+    outputs: y, gamma, beta, loss, acc, bits  (loss/acc/bits are zero-size dummies when b is None)
+    """
+
+    @staticmethod
+    def forward(ctx, xhat, weight, skey, key, b, m, alpha, relu, stride, pad):
+        xhat, weight = xhat.contiguous(), weight.contiguous()
+        bb = None if b is None else b.contiguous().view(-1)
+        y, gamma, beta, loss, acc, bits = kernels.passport_fwd(xhat, weight, m, bb, float(alpha), relu)
+        ctx.save_for_backward(xhat, weight, gamma, beta, m, bb)
+        ctx.cfg = (float(alpha), relu, stride, pad, tuple(key.shape))
+        if bb is None:
+            loss = acc = xhat.new_zeros(())
+            bits = torch.zeros(0, dtype=torch.int8, device=xhat.device)
+        ctx.mark_non_differentiable(acc, bits)
+        return y, gamma, beta, loss, acc, bits
+
+    @staticmethod
+    def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
+        xhat, weight, gamma, beta, m, bb = ctx.saved_tensors
+        alpha, relu, stride, pad, key_shape = ctx.cfg
+        if dy is None:
+            dy = torch.zeros_like(xhat)
+        dl = None if (bb is None or dloss is None) else dloss.contiguous()
+        dx, dw, dg, db = kernels.passport_bwd(dy.contiguous(), xhat, gamma, beta, m, bb, alpha, dl,
+                                              _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
+                                              weight.shape, relu)
+        dsk = dk = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dsk, dk = kernels.gamma_beta_dkey(dg, db, weight, key_shape, stride, pad)
+        return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None)
+
+
+def affine_relu(xhat, gamma, beta, relu=True):
+    return _AffineReLU.apply(xhat, gamma.reshape(-1), beta.reshape(-1), bool(relu))
+
+
+def gamma_beta(weight, skey, key, m, stride, pad):
+    return _GammaBeta.apply(weight, skey, key, m, stride, pad)
+
+
+def sign_loss(gamma, b, alpha, l2=L2):
+    """-> (loss, acc, bits): loss = sum(alpha*relu(-b*gamma+0.1)) + l2*sum(gamma^2)."""
+    return _SignLoss.apply(gamma, b, alpha, l2)
+
+
+def passport_layer(xhat, weight, skey, key, b, m, alpha, relu, stride, pad):
+    return _PassportLayer.apply(xhat, weight, skey, key, b, m, alpha, bool(relu), stride, pad)

@@ -1,0 +1,129 @@
+/* deepipr_hip.h -- C ABI of the MI355X (gfx950) passport-layer kernels.
+ *
+ * Drop-in boundary of the DeepIPR hot path (reference kamwoh/DeepIPR, a pure-Python/PyTorch
+ * code base with no FFI of its own).  Each entry point replaces a run of stock
+ * ATen ops inside one reference method; the file:line after "replaces" is that run.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory (HBM) unless named host_*
+ *   - all tensors fp32, dense, NCHW / OIHW; `HW` = H*W of the activation plane
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it: no
+ *     allocation, no synchronisation, no global mutable state -> re-entrant and capturable in a
+ *     hipGraph.  Scratch memory is passed in by the caller (`*_workspace_bytes` gives its size).
+ *   - return value: DEEPIPR_OK (0) or a negative DEEPIPR_E* code; deepipr_last_error() returns a
+ *     thread-local message for the last failing call on this thread.
+ *   - inputs are never written; outputs are fully overwritten (no accumulate-into).
+ *   - reductions are fixed-order (no float atomics): results are bit-reproducible run to run.
+ */
+#ifndef DEEPIPR_HIP_H
+#define DEEPIPR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEEPIPR_OK 0
+#define DEEPIPR_EINVAL (-1)   /* bad shape / null pointer / misaligned pointer / workspace too small */
+#define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+#define DEEPIPR_ABI_VERSION 1
+
+int deepipr_abi_version(void);
+const char *deepipr_last_error(void);
+
+/* ------------------------------------------------------------------ passport conv -> global pool
+ * m[k] = mean over (b, oh, ow) of im2col(key)[b, k, (oh,ow)], k = (ci*kh + r)*kw + q, kept in f64,
+ * for `nkeys` passport tensors of identical shape laid out back to back.  Because conv and the two
+ * means are linear, gamma = W_mat . m (see below).  Keys are constant buffers during training, so
+ * the host caches `m` per key version.
+ * replaces: the im2col half of self.conv(skey) / self.conv(key),
+ *           models/layers/passportconv2d.py:148,169 (private twin :146,167).
+ * keys  [nkeys][B][Ci][H][W]   m_out [nkeys][Ci*kh*kw] (double) */
+int deepipr_pooled_patch_mean(const float *keys, int nkeys, int B, int Ci, int H, int W,
+                              int kh, int kw, int stride, int pad, double *m_out, void *stream);
+
+/* gamma[co] = sum_k W[co,k]*m_scale[k],  beta[co] likewise with m_bias; f64 accumulation, one
+ * rounding to f32 at the end.
+ * replaces: conv -> view(b,c,-1).mean(2) -> mean(0), passportconv2d.py:148-152 (get_scale) and
+ *           :169-173 (get_bias); private twin passportconv2d_private.py:146-150,167-171.
+ * W [Co][K]   m [2][K] double (scale key first)   gamma, beta [Co] */
+int deepipr_gamma_beta_fwd(const float *W, const double *m, int Co, int K,
+                           float *gamma, float *beta, void *stream);
+
+/* dW[co,k] = dgamma[co]*m_scale[k] + dbeta[co]*m_bias[k]: the passport branch's
+ * contribution to the shared conv weight's gradient (autograd adds the data conv's wgrad).
+ * replaces: the two convolution_backward(wgrad) + mean backward chains of passportconv2d.py:148-152,
+ *           169-173.   dW [Co][K] */
+int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double *m,
+                           int Co, int K, float *dW, void *stream);
+
+/* Gradient w.r.t. the passport tensors themselves (keys made nn.Parameters by
+ * passport_attack_3.py:232-243).  dkeys[j][b][ci][ih][iw] = sum over patches covering (ih,iw) of
+ * (sum_co d[j][co]*W[co,ci,r,q]) * inv_n,  d[0]=dgamma (scale key), d[1]=dbeta (bias key).
+ * workspace: deepipr_gamma_beta_dkey_workspace_bytes().   dkeys [2][B][Ci][H][W] */
+size_t deepipr_gamma_beta_dkey_workspace_bytes(int Ci, int kh, int kw);
+int deepipr_gamma_beta_dkey(const float *dgamma, const float *dbeta, const float *W, int Co,
+                            int B, int Ci, int H, int Wd, int kh, int kw, int stride, int pad,
+                            float *dkeys, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------ passport affine (+ReLU)
+ * y = gamma[c]*xhat + beta[c] (separate mul and add roundings, as ATen's mul, add), ReLU if relu!=0.
+ * replaces: `scale * x + bias` and relu_, passportconv2d.py:220-222 (private :217-218).
+ * One pass: 8 B / element of HBM traffic.  xhat, y [N][C][HW] */
+int deepipr_affine_relu_fwd(const float *xhat, const float *gamma, const float *beta, float *y,
+                            int N, int C, int HW, int relu, void *stream);
+
+/* dxhat = dy*mask*gamma, dgamma[c] = sum(dy*mask*xhat), dbeta[c] = sum(dy*mask); the ReLU mask is
+ * recomputed as gamma*xhat+beta > 0 (relu'(0)=0).  One pass over dy and xhat (12 B / element) plus a
+ * fixed-order finish over the per-split partial sums.
+ * replaces: threshold_backward, mul/sum backward of passportconv2d.py:220-222.
+ * workspace: deepipr_affine_relu_bwd_workspace_bytes(N, C, HW) bytes. */
+size_t deepipr_affine_relu_bwd_workspace_bytes(int N, int C, int HW);
+int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gamma, const float *beta,
+                            float *dxhat, float *dgamma, float *dbeta, int N, int C, int HW, int relu,
+                            void *workspace, void *stream);
+
+/* ------------------------------------------------------------------ hinge sign loss on gamma
+ * loss = sum_c alpha*relu(-b*gamma + margin) + l2*sum_c gamma^2;  acc = mean(sign(b) == sign(gamma));
+ * bits[c] = sign(gamma[c]) in {-1,0,+1}.
+ * replaces: SignLoss.add / get_loss / get_acc, models/losses/sign_loss.py:20,27,52-54 and the
+ *           signature read-out experiments/trainer_private.py:50,57.
+ * gamma, b [C]; loss, acc: one float each; bits [C] int8 (may be NULL). */
+int deepipr_sign_loss_fwd(const float *gamma, const float *b, float alpha, float margin, float l2,
+                          int C, float *loss, float *acc, int8_t *bits, void *stream);
+
+/* dgamma[c] = dloss * ( -alpha*b*[ -b*gamma+margin > 0 ] + 2*l2*gamma ).  `dloss` is a device scalar
+ * (the upstream gradient), so no host synchronisation is needed. */
+int deepipr_sign_loss_bwd(const float *dloss, const float *gamma, const float *b, float alpha,
+                          float margin, float l2, int C, float *dgamma, void *stream);
+
+/* ------------------------------------------------------------------ fused layer entry points
+ * Forward of one passport layer after the norm: gamma/beta from the pooled sums, sign loss, affine.
+ *   launch 1: gamma_beta (one workgroup per output channel row)
+ *   launch 2: affine+ReLU over xhat; workgroup 0 also emits loss / acc / bits.
+ * loss/acc/bits may be NULL when the layer has no sign loss (alpha == 0, passportconv2d.py:45-48). */
+int deepipr_passport_fwd(const float *xhat, const float *W, const double *m,
+                         const float *b, float alpha, float margin, float l2,
+                         int N, int C, int HW, int K, int relu,
+                         float *y, float *gamma, float *beta, float *loss, float *acc, int8_t *bits,
+                         void *stream);
+
+/* Backward of the same: launch 1 = affine backward (dxhat + per-split partial sums), launch 2 =
+ * finish the partial sums, add dgamma_extra / dbeta_extra (gradients arriving at gamma / beta from
+ * elsewhere, may be NULL) and the sign-loss gradient (scaled by the device scalar *dloss, NULL = no sign loss), write
+ * dgamma/dbeta and the rank-2 update dW.  workspace: deepipr_passport_bwd_workspace_bytes(). */
+size_t deepipr_passport_bwd_workspace_bytes(int N, int C, int HW);
+int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma, const float *beta,
+                         const double *m, const float *b, float alpha, float margin, float l2,
+                         const float *dloss, const float *dgamma_extra, const float *dbeta_extra,
+                         int N, int C, int HW, int K, int relu,
+                         float *dxhat, float *dW, float *dgamma, float *dbeta,
+                         void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPIPR_HIP_H */

@@ -39,3 +39,45 @@ class OracleImpl:
 
     def test_signature(self, model):
         return {k: v[1] for k, v in torch_ref.signature_report(model).items()}
+
+
+class ProductImpl:
+    """The HIP build (deepipr_amd).  On the GPU box it runs the real kernels on cuda:0; the CPU suite
+    passes device='cpu' after monkeypatching passport_ops.kernels with tests/oracle_kernels.py."""
+
+    def __init__(self, device='cuda:0'):
+        self.device = torch.device(device)
+
+    def build(self, case):
+        from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+        from deepipr_amd.models.alexnet_passport import AlexNetPassport
+        from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+        from deepipr_amd.models.resnet_passport import ResNet18Passport
+        from deepipr_amd.models.resnet_passport_private import ResNet18Private
+        kw = construct_passport_kwargs_from_dict({'passport_config': case['config'], 'norm_type': case['norm'],
+                                                  'key_type': 'random', 'sl_ratio': ALPHA})
+        private = case['scheme'] != 1
+        if case['arch'] == 'alexnet':
+            model = (AlexNetPassportPrivate if private else AlexNetPassport)(3, case['ncls'], kw)
+        else:
+            model = (ResNet18Private if private else ResNet18Passport)(num_classes=case['ncls'], passport_kwargs=kw)
+        return model.to(self.device)
+
+    def is_passport(self, m):
+        from deepipr_amd.models._builders import PASSPORT_TYPES
+        return isinstance(m, PASSPORT_TYPES)
+
+    def is_private(self, m):
+        from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
+        return isinstance(m, PassportPrivateBlock)
+
+    def step(self, model, opt, batch, wm):
+        from deepipr_amd.experiments.trainer import Trainer
+        from deepipr_amd.experiments.trainer_private import TrainerPrivate
+        private = any(self.is_private(m) for m in model.modules())
+        tr = (TrainerPrivate if private else Trainer)(model, opt, None, self.device)
+        return tr.train(0, [batch], [wm] if wm is not None else None)
+
+    def test_signature(self, model):
+        from deepipr_amd.experiments.trainer_private import TesterPrivate
+        return TesterPrivate(model, self.device, verbose=False).test_signature()

@@ -1,0 +1,87 @@
+"""A stand-in for deepipr_amd.passport_ops.kernels built from oracle/np_passport.py.
+
+TEST-ONLY: lets the CPU suite exercise the *host* logic of the product (autograd wiring, module API,
+trainers, DDP) without a GPU by monkeypatching `passport_ops.kernels`.  The product itself never
+imports this; on a GPU box the real HIP kernels run (tests/test_parity_gpu.py).
+"""
+import numpy as np
+import torch
+
+from oracle import np_passport as npp
+
+
+def _n(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _t(a, like, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(like.device)
+
+
+class OracleKernels:
+    def pooled_patch_mean(self, keys, kh, kw, stride, pad):
+        out = []
+        for j in range(keys.shape[0]):
+            s, n = npp.pooled_patch_sum(_n(keys[j]), kh, kw, stride, pad)
+            out.append(s / n)
+        return _t(np.stack(out), keys, torch.float64)
+
+    def gamma_beta_fwd(self, weight, m):
+        w = _n(weight).reshape(weight.shape[0], -1)
+        mm = _n(m)
+        return _t(w @ mm[0], weight), _t(w @ mm[1], weight)
+
+    def gamma_beta_bwd(self, dgamma, dbeta, m, wshape):
+        mm = _n(m)
+        dw = np.outer(_n(dgamma), mm[0]) + np.outer(_n(dbeta), mm[1])
+        return _t(dw.reshape(tuple(wshape)), dgamma)
+
+    def gamma_beta_dkey(self, dgamma, dbeta, weight, key_shape, stride, pad):
+        z = np.zeros(tuple(key_shape))
+        _, dsk, dk = npp.gamma_beta_bwd(_n(dgamma), _n(dbeta), _n(weight), z, z, stride, pad, need_dkey=True)
+        return _t(dsk, weight), _t(dk, weight)
+
+    def affine_relu_fwd(self, xhat, gamma, beta, relu):
+        y = npp.affine_relu_fwd(xhat.detach().numpy(), gamma.detach().numpy().reshape(-1),
+                                beta.detach().numpy().reshape(-1), relu)     # f32, like the kernel
+        return _t(y, xhat)
+
+    def affine_relu_bwd(self, dy, xhat, gamma, beta, relu):
+        g32, b32 = gamma.detach().numpy().reshape(-1), beta.detach().numpy().reshape(-1)
+        mask_src = npp.affine_relu_fwd(xhat.detach().numpy(), g32, b32, False)
+        dyn = _n(dy)
+        dz = np.where(mask_src > 0, dyn, 0.0) if relu else dyn
+        dx = dz * _n(gamma).reshape(1, -1, 1, 1)
+        return (_t(dx, xhat), _t((dz * _n(xhat)).sum(axis=(0, 2, 3)), xhat), _t(dz.sum(axis=(0, 2, 3)), xhat))
+
+    def sign_loss_fwd(self, gamma, b, alpha, margin=npp.MARGIN, l2=npp.L2):
+        g, bb = _n(gamma).reshape(-1), _n(b).reshape(-1)
+        z32 = (-b.detach().numpy().reshape(-1) * gamma.detach().numpy().reshape(-1) + np.float32(margin))
+        loss = (alpha * np.maximum(z32.astype(np.float64), 0)).sum() + l2 * (g ** 2).sum()
+        acc = (np.sign(bb) == np.sign(g)).mean()
+        return (_t(np.float64(loss), gamma).reshape(()), _t(np.float64(acc), gamma).reshape(()),
+                _t(np.sign(g), gamma, torch.int8))
+
+    def sign_loss_bwd(self, dloss, gamma, b, alpha, margin=npp.MARGIN, l2=npp.L2):
+        z32 = (-b.detach().numpy().reshape(-1) * gamma.detach().numpy().reshape(-1) + np.float32(margin))
+        g = np.where(z32 > 0, -alpha * _n(b).reshape(-1), 0.0) + 2 * l2 * _n(gamma).reshape(-1)
+        return _t(float(dloss) * g, gamma)
+
+    def passport_fwd(self, xhat, weight, m, b, alpha, relu, margin=npp.MARGIN, l2=npp.L2):
+        gamma, beta = self.gamma_beta_fwd(weight, m)
+        y = self.affine_relu_fwd(xhat, gamma, beta, relu)
+        if b is None:
+            return y, gamma, beta, None, None, None
+        loss, acc, bits = self.sign_loss_fwd(gamma, b, alpha, margin, l2)
+        return y, gamma, beta, loss, acc, bits
+
+    def passport_bwd(self, dy, xhat, gamma, beta, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu,
+                     margin=npp.MARGIN, l2=npp.L2):
+        dx, dg, db = self.affine_relu_bwd(dy, xhat, gamma, beta, relu)
+        if dgamma_extra is not None:
+            dg = dg + dgamma_extra
+        if dbeta_extra is not None:
+            db = db + dbeta_extra
+        if dloss is not None:
+            dg = dg + self.sign_loss_bwd(dloss, gamma, b, alpha, margin, l2)
+        return dx, self.gamma_beta_bwd(dg, db, m, wshape), dg, db

@@ -1,0 +1,158 @@
+"""CPU tests of the product's HOST logic (module API, autograd wiring, trainers, config surface).
+
+The HIP kernels cannot run here, so `passport_ops.kernels` is monkeypatched with the oracle-backed
+stand-in of tests/oracle_kernels.py; everything above the kernel boundary is the shipped code.  The
+same cases run through the real kernels in tests/test_parity_gpu.py."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import runner
+from oracle.cases import CASES
+from tests.compare import compare_case
+from tests.impls import ProductImpl, load_golden
+from tests.oracle_kernels import OracleKernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def cpu_kernels(monkeypatch):
+    from deepipr_amd import passport_ops
+    monkeypatch.setattr(passport_ops, 'kernels', OracleKernels())
+    return passport_ops
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the un-patched product raises on host tensors."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
+    with pytest.raises(RuntimeError, match='GPU only'):
+        blk(torch.randn(2, 4, 8, 8))
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_host_wiring_matches_reference(name, golden_dir, cpu_kernels):
+    torch.set_num_threads(8)
+    gold = load_golden(golden_dir, name)
+    got = runner.collect(name, ProductImpl('cpu'))
+    compare_case(got, gold, rtol=2e-5, atol=2e-6, skip_prefixes=('train/acc',))
+    # same torch seed -> same constructor RNG draws as the reference: signature vectors identical
+    for k in gold:
+        if k.startswith('ctor_b/'):
+            assert np.array_equal(got[k], gold[k]), k
+    for k in ('train/acc', 'train/acc_public', 'train/acc_private'):
+        if k in gold:
+            assert got[k] == pytest.approx(float(gold[k]), abs=1e-4)
+
+
+def test_passport_selection_and_set_key(golden_dir):
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    gold = load_golden(golden_dir, 'blocks')
+    blk = PassportBlock(8, 16, 3, 2, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.5}, relu=False)
+    cands = torch.arange(5 * 6 * 2 * 2, dtype=torch.float32).view(5, 6, 2, 2)
+    random.seed(1234)
+    assert np.array_equal(blk.passport_selection(cands).numpy(), gold['selection/c6'])
+    cands3 = torch.arange(5 * 3 * 2 * 2, dtype=torch.float32).view(5, 3, 2, 2)
+    random.seed(1234)
+    assert np.array_equal(blk.passport_selection(cands3).numpy(), gold['selection/c3'])
+    random.seed(99)
+    blk.set_key(cands, cands + 1000)
+    assert np.array_equal(blk.key.numpy(), gold['selection/set_key_key'])
+    assert np.array_equal(blk.skey.numpy(), gold['selection/set_key_skey'])
+
+
+def test_block_level_bk3(golden_dir, cpu_kernels):
+    """Key batch 3 (mean over b), stride 2, relu=False, alpha 0.5: y, gamma, beta, sign loss, dW, dx."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    gold = load_golden(golden_dir, 'blocks')
+    rs = np.random.RandomState(7)
+    w = torch.from_numpy(rs.standard_normal((16, 8, 3, 3)).astype(np.float32) * 0.2)
+    key = torch.from_numpy(rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32))
+    skey = torch.from_numpy(rs.uniform(-1, 1, (3, 8, 9, 9)).astype(np.float32))
+    x = torch.from_numpy(rs.standard_normal((5, 8, 9, 9)).astype(np.float32)).requires_grad_(True)
+    cot = torch.from_numpy(rs.standard_normal((5, 16, 5, 5)).astype(np.float32))
+    b = torch.from_numpy(np.where(rs.uniform(size=16) < 0.5, -1.0, 1.0).astype(np.float32))
+    blk = PassportBlock(8, 16, 3, 2, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.5}, relu=False)
+    with torch.no_grad():
+        blk.weight.copy_(w)
+        blk.b.copy_(b)
+        blk.sign_loss.b.copy_(b)
+    blk.register_buffer('key', key)
+    blk.register_buffer('skey', skey)
+    y = blk(x)
+    ((y * cot).sum() + blk.sign_loss.loss).backward()
+    from tests.compare import close
+    close(y.detach().numpy(), gold['bk3/y'], 'y', 2e-5, 2e-6)
+    close(blk.sign_loss.scale_cache.detach().numpy().reshape(-1), gold['bk3/gamma'], 'gamma', 2e-5, 2e-6)
+    close(blk.get_bias().detach().numpy().reshape(-1), gold['bk3/beta'], 'beta', 2e-5, 2e-6)
+    close(float(blk.sign_loss.loss), gold['bk3/sign_loss'], 'loss', 2e-5, 2e-6)
+    close(blk.weight.grad.numpy(), gold['bk3/dW'], 'dW', 1e-4, 1e-5)
+    close(x.grad.numpy(), gold['bk3/dx'], 'dx', 1e-4, 1e-5)
+
+
+def test_trainable_keys_get_gradients(cpu_kernels):
+    """passport_attack_3.py:232-243 turns the keys into nn.Parameters: d/dkey must flow."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    torch.manual_seed(3)
+    blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.1})
+    blk.key = torch.nn.Parameter(torch.rand(1, 4, 6, 6) * 2 - 1)
+    blk.skey = torch.nn.Parameter(torch.rand(1, 4, 6, 6) * 2 - 1)
+    x = torch.randn(3, 4, 6, 6)
+    y = blk(x)
+    (y.square().sum() + blk.sign_loss.loss).backward()
+    ref_w = blk.weight.detach().clone().requires_grad_(True)
+    ks, kb = blk.skey.detach().clone().requires_grad_(True), blk.key.detach().clone().requires_grad_(True)
+    conv = lambda t: torch.nn.functional.conv2d(t, ref_w, None, 1, 1)
+    g = conv(ks).mean(dim=(0, 2, 3))
+    bt = conv(kb).mean(dim=(0, 2, 3))
+    yy = torch.relu(g.view(1, -1, 1, 1) * conv(x) + bt.view(1, -1, 1, 1))
+    sl = (0.1 * torch.relu(-blk.b * g + 0.1)).sum() + 1e-5 * g.pow(2).sum()
+    (yy.square().sum() + sl).backward()
+    assert torch.allclose(blk.skey.grad, ks.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(blk.key.grad, kb.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(blk.weight.grad, ref_w.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_state_dict_roundtrip_presizes_lazy_tensors(cpu_kernels):
+    """_load_from_state_dict pre-sizes key/skey/scale/bias so a strict load works on a fresh model
+    (passportconv2d.py:177-196)."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
+    kw = {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1}
+    for cls, names in ((PassportBlock, ('key', 'skey')), (PassportPrivateBlock, ('key_private', 'skey_private'))):
+        a = cls(4, 16, 3, 1, 1, kw)
+        a(torch.randn(2, 4, 8, 8))
+        sd = a.state_dict()
+        for n in names:
+            assert n in sd and tuple(sd[n].shape) == (1, 4, 8, 8)
+        b = cls(4, 16, 3, 1, 1, kw)
+        b.load_state_dict(sd, strict=True)
+        for k in sd:
+            assert torch.equal(b.state_dict()[k], sd[k]), k
+    a = PassportBlock(4, 16, 3, 1, 1, kw)
+    a.init_scale(True)
+    a.init_bias(True)
+    b = PassportBlock(4, 16, 3, 1, 1, kw)
+    b.load_state_dict(a.state_dict(), strict=True)
+    assert isinstance(b.scale, torch.nn.Parameter) and isinstance(b.bias, torch.nn.Parameter)
+
+
+def test_passport_kwargs_builder_matches_reference_shape():
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
+    kw, keys = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'shuffle',
+                                                    'sl_ratio': 0.1}, need_index=True)
+    assert keys == ['layer4.0.convbnrelu_1', 'layer4.0.convbn_2', 'layer4.0.shortcut', 'layer4.1.convbnrelu_1',
+                    'layer4.1.convbn_2']
+    assert kw['layer4']['0']['shortcut'] == {'flag': True, 'norm_type': 'bn', 'key_type': 'shuffle', 'sign_loss': 0.1}
+    assert kw['convbnrelu_1']['flag'] is False
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'alexnet_passport.json')))
+    cfg['4'] = 'abc'
+    kw, keys = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'gn', 'key_type': 'random',
+                                                    'sl_ratio': 0.5}, need_index=True)
+    assert keys == ['4', '5', '6'] and kw['4']['b'] == 'abc' and kw['4']['flag'] is True
