@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the DeepIPR passport train step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ResNet18 V1 passport (passport_configs/resnet18_passport.json, the 5
+layer4 passport layers), CIFAR10-shaped synthetic batches of 128 per GPU resident in HBM, fp32, one step =
+zero_grad -> forward -> CE + sum of sign losses -> backward -> SGD(0.01, 0.9, wd 1e-4)
+(reference experiments/trainer.py:128-145).  Weak scaling: every rank keeps a batch of 128.
+
+Rank 0 prints ONE JSON line with the whole-job images/sec, plus
+  roofline      the dominant hand-written kernel (passport affine backward), timed in situ with HIP
+                events on its launch stream during the timed region
+  cpu_baseline  the oracle's CPU step ("port") on this host's cores, bounded sample, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from deepipr_amd import _lib, distributed as D                                    # noqa: E402
+from deepipr_amd.experiments.trainer import train_step_v1                          # noqa: E402
+from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23     # noqa: E402
+from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict      # noqa: E402
+from deepipr_amd.models._builders import PASSPORT_TYPES                            # noqa: E402
+from deepipr_amd.models.resnet_passport import ResNet18Passport                    # noqa: E402
+from deepipr_amd.models.resnet_passport_private import ResNet18Private             # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+BYTES_PER_ELT = {'affine_bwd': 12, 'affine_fwd': 8}     # read dy + xhat, write dxhat / read, write
+
+
+def build_model(args, device):
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': 0.1})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    if args.scheme == 1:
+        model = ResNet18Passport(num_classes=args.classes, passport_kwargs=kw)
+    else:
+        model = ResNet18Private(num_classes=args.classes, passport_kwargs=kw)
+    return model.to(device)
+
+
+def passport_elements(model, batch):
+    """Activation elements of every passport layer for one batch (for the algorithmic byte count)."""
+    sizes = []
+    hooks = []
+    for m in model.modules():
+        if isinstance(m, PASSPORT_TYPES):
+            hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel())))
+    with torch.no_grad():
+        model(batch)
+    for h in hooks:
+        h.remove()
+    return sizes
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota), capped at 32."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return min(n, 32)
+
+
+def cpu_baseline(args, budget_s=20.0):
+    """The oracle's plain-PyTorch CPU step on the same workload, bounded to ~budget_s seconds."""
+    from oracle import torch_ref
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
+    kw = torch_ref.passport_kwargs_from_config(cfg, 'bn', 'random', 0.1)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    # Host threads = the cores the cgroup grants (16 on the GPU box: 256 logical CPUs visible, cpu.max
+    # quota 16; running oneDNN on all 256 visible threads took 75 s per step).
+    threads = int(os.environ.get('DEEPIPR_CPU_THREADS', host_cores()))
+    torch.set_num_threads(threads)
+    model = torch_ref.resnet18_ref(num_classes=args.classes, passport_kwargs=kw, private=args.scheme != 1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(args.batch, 3, 32, 32, generator=g)
+    y = torch.randint(0, args.classes, (args.batch,), generator=g)
+    step = torch_ref.v1_step if args.scheme == 1 else torch_ref.v23_step
+    model.train()
+    step(model, opt, x, y)                                  # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(model, opt, x, y)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 50:
+            break
+    return {'value': round(n * args.batch / dt, 2), 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d steps of batch %d (%.1f s) of oracle/torch_ref.py on %d host threads, torch %s'
+                      % (n, args.batch, dt, threads, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
+    ap.add_argument('--scheme', type=int, default=1, choices=[1, 2])
+    ap.add_argument('--classes', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    rank, local_rank, world = D.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)' % (args.gpus, world))
+        args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True                  # MIOpen find-mode, as train_v1.py:8
+
+    model = build_model(args, device)
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    nb = 4                                                  # distinct synthetic batches, resident in HBM
+    xs = [torch.randn(args.batch, 3, 32, 32, generator=g).to(device) for _ in range(nb)]
+    ys = [torch.randint(0, args.classes, (args.batch,), generator=g).to(device) for _ in range(nb)]
+    model.train()
+    elems = passport_elements(model, xs[0])                 # also materialises the random keys
+    if args.scheme == 1:
+        net = D.replicate(model, device)
+        step = lambda i: train_step_v1(net, opt, xs[i % nb], ys[i % nb])
+    else:
+        net = D.replicate(DualBranch(model), device)
+        step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+
+    for i in range(args.warmup):
+        step(i)
+    timing = not args.no_kernel_timing
+    D.barrier()
+    torch.cuda.synchronize()
+    if timing:
+        _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read() if timing else {}
+    if timing:
+        _lib.profile_enable(False)
+    dt = D.max_over_ranks(dt, device)
+
+    if rank != 0:
+        return
+    value = args.gpus * args.batch * args.steps / dt
+    fwd_per_step = 1 if args.scheme == 1 else 2
+    out = {
+        'metric': 'images/sec ResNet18-passport CIFAR10 train step', 'value': round(value, 1), 'unit': 'img/s',
+        'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'ResNet18 V%s passport (resnet18_passport.json: 5 layer4 passport layers), '
+                               'CIFAR%d 3x32x32, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
+                               ('1' if args.scheme == 1 else '2 private', args.classes, args.batch),
+                   'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
+                   'passport_layers': len(elems)},
+    }
+    if timing and prof.get('affine_bwd', (0, 0))[1] > 0:
+        per_launch_elems = float(np.mean(elems))
+        kern = {}
+        for name, bpe in BYTES_PER_ELT.items():
+            ms, n = prof[name]
+            if n:
+                us = 1000.0 * ms / n
+                kern[name] = {'avg_us': round(us, 3), 'launches': n,
+                              'GBps': round(bpe * per_launch_elems / (us * 1e-6) / 1e9, 1)}
+        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials'):
+            ms, n = prof.get(name, (0, 0))
+            if n:
+                kern[name] = {'avg_us': round(1000.0 * ms / n, 3), 'launches': n}
+        a = kern['affine_bwd']
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_affine_bwd (passport affine backward)',
+                           'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(a['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                           'bytes_per_launch': int(12 * per_launch_elems), 'avg_us': a['avg_us'],
+                           'note': '12 B/elt x %d elts per launch; tensors are %.1f MB (L2/MALL-resident, '
+                                   'launch-latency bound at this shape)' % (per_launch_elems,
+                                                                           4 * per_launch_elems / 1e6)}
+        out['kernels'] = kern
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,12 @@ op raises HipLibraryMissing.
 import ctypes
 import os
 
+# torch must be imported (and with it torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) BEFORE our
+# library is dlopen'ed: the dynamic linker then binds our NEEDED libamdhip64.so.7 to the runtime torch
+# already uses.  The other order loads /opt/rocm's copy as a second HIP runtime in the process, which
+# cannot see torch's device context ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libdeepipr_hip.so')
 
@@ -18,6 +24,8 @@ _int, _flt, _sz = _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     'deepipr_abi_version': (_int, []),
     'deepipr_last_error': (_c.c_char_p, []),
+    'deepipr_profile_enable': (_int, [_int]),
+    'deepipr_profile_read': (_int, [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
     'deepipr_pooled_patch_mean': (_int, [_f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f64p, _vp]),
     'deepipr_gamma_beta_fwd': (_int, [_f32p, _f64p, _int, _int, _f32p, _f32p, _vp]),
     'deepipr_gamma_beta_bwd': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
@@ -77,3 +85,21 @@ def check(rc, what):
     if rc != 0:
         msg = lib().deepipr_last_error()
         raise RuntimeError('deepipr_hip.%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
+                   'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey']
+
+
+def profile_enable(on):
+    check(lib().deepipr_profile_enable(int(on)), 'profile_enable')
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} since the last profile_enable(True)."""
+    out = {}
+    for i, name in enumerate(PROFILE_KERNELS):
+        ms, n = ctypes.c_double(), ctypes.c_longlong()
+        check(lib().deepipr_profile_read(i, ctypes.byref(ms), ctypes.byref(n)), 'profile_read')
+        out[name] = (ms.value, n.value)
+    return out

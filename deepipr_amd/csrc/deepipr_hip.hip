@@ -23,6 +23,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
+#include <vector>
 
 #include "../../include/deepipr_hip.h"
 
@@ -50,6 +52,46 @@ int check_launch(const char *what) {
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// Opt-in in-situ kernel timing (deepipr_profile_*): when enabled, every launch is bracketed by two
+// hipEvents recorded on the launch stream; durations are read back later with deepipr_profile_read.
+// Off by default (one relaxed bool load per launch); must stay off during hipGraph capture.
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    struct Pending { int k; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    double total_ms[DEEPIPR_PROFILE_KERNELS] = {};
+    long long launches[DEEPIPR_PROFILE_KERNELS] = {};
+};
+ProfState g_prof;
+
+struct ProfScope {
+    int k;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int kernel, hipStream_t stream) : k(kernel), st(stream) {
+        if (!g_prof.on) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!g_prof.pool.empty()) { e = g_prof.pool.back(); g_prof.pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = take();
+        b = take();
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.pending.push_back({k, a, b});
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Exact unsigned division by a launch-time constant (n < 2^31): q = (n * M) >> S.
@@ -616,6 +658,7 @@ int launch_affine_fwd(const float *xhat, const float *gamma, const float *beta, 
     const size_t total = static_cast<size_t>(N) * C * HW;
     if (total >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "affine_relu_fwd: tensor has >= 2^31 elements");
     const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
+    ProfScope prof(DEEPIPR_K_AFFINE_FWD, st);
     const bool vec = (HW % 4 == 0) && aligned16(xhat) && aligned16(y);
     if (vec) {
         const unsigned n4 = static_cast<unsigned>(total / 4);
@@ -663,6 +706,7 @@ int launch_affine_bwd(const float *dy, const float *xh, const float *g, const fl
     const bool can_vec = aligned16(dy) && aligned16(xh) && aligned16(dx);
     const BwdPlan pl = plan_bwd(N, C, P, can_vec);
     if (pl.NS > 65535) return fail(DEEPIPR_EINVAL, "affine_relu_bwd: too many batch splits");
+    ProfScope prof(DEEPIPR_K_AFFINE_BWD, st);
     if (pl.VEC == 4) {
         if (relu) launch_bwd_t<4, true>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
         else launch_bwd_t<4, false>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
@@ -694,6 +738,34 @@ int deepipr_abi_version(void) { return DEEPIPR_ABI_VERSION; }
 
 const char *deepipr_last_error(void) { return g_err; }
 
+int deepipr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (on) {
+        for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) { g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; }
+    }
+    g_prof.on = on != 0;
+    return DEEPIPR_OK;
+}
+
+int deepipr_profile_read(int kernel, double *total_ms, long long *launches) {
+    if (kernel < 0 || kernel >= DEEPIPR_PROFILE_KERNELS || !total_ms || !launches)
+        return fail(DEEPIPR_EINVAL, "profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto &p : g_prof.pending) {           // drain everything recorded so far
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof.total_ms[p.k] += ms;
+            g_prof.launches[p.k] += 1;
+        }
+        g_prof.pool.push_back(p.a);
+        g_prof.pool.push_back(p.b);
+    }
+    g_prof.pending.clear();
+    *total_ms = g_prof.total_ms[kernel];
+    *launches = g_prof.launches[kernel];
+    return DEEPIPR_OK;
+}
+
 int deepipr_pooled_patch_mean(const float *keys, int nkeys, int B, int Ci, int H, int W, int kh, int kw,
                               int stride, int pad, double *m_out, void *stream) {
     if (!keys || !m_out || nkeys <= 0 || B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 ||
@@ -703,6 +775,7 @@ int deepipr_pooled_patch_mean(const float *keys, int nkeys, int B, int Ci, int H
     if (Ho <= 0 || Wo <= 0) return fail(DEEPIPR_EINVAL, "pooled_patch_mean: empty conv output");
     const int K = Ci * kh * kw;
     const dim3 grid((K + 3) / 4, nkeys);
+    ProfScope prof(DEEPIPR_K_POOLED_PATCH_MEAN, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_pooled_patch_mean, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream), keys,
                        B, Ci, H, W, kh, kw, stride, pad, Ho, Wo, m_out);
     return check_launch("pooled_patch_mean");
@@ -712,6 +785,7 @@ int deepipr_gamma_beta_fwd(const float *W, const double *s, int Co, int K, float
                            void *stream) {
     if (!W || !s || !gamma || !beta || Co <= 0 || K <= 0) return fail(DEEPIPR_EINVAL, "gamma_beta_fwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
     if (K % 4 == 0 && aligned16(W) && aligned16(s))
         hipLaunchKernelGGL(k_gamma_beta<true>, dim3(Co), dim3(kThreads), 0, st, W, s, K, gamma, beta);
     else
@@ -724,6 +798,7 @@ int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double
     if (!dgamma || !dbeta || !s || !dW || Co <= 0 || K <= 0)
         return fail(DEEPIPR_EINVAL, "gamma_beta_bwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
     if (K % 4 == 0 && aligned16(dW) && aligned16(s))
         hipLaunchKernelGGL(k_gamma_beta_bwd<true>, dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, K, dW);
     else
@@ -746,6 +821,7 @@ int deepipr_gamma_beta_dkey(const float *dgamma, const float *dbeta, const float
     const int K = Ci * kh * kw;
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *part = static_cast<double *>(workspace);
+    ProfScope prof(DEEPIPR_K_DKEY, st);
     hipLaunchKernelGGL(k_dkey_colsum, dim3((K + kThreads - 1) / kThreads, kDkeySplit), dim3(kThreads), 0, st,
                        dgamma, dbeta, W, Co, K, part);
     const int total = 2 * B * Ci * H * Wd;
@@ -778,6 +854,7 @@ int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gam
     double *part = static_cast<double *>(workspace);
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
+    ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
     hipLaunchKernelGGL(k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part,
                        pl.NS, C, dgamma, dbeta);
     return check_launch("affine_relu_bwd(finish)");
@@ -786,6 +863,7 @@ int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gam
 int deepipr_sign_loss_fwd(const float *gamma, const float *b, float alpha, float margin, float l2, int C,
                           float *loss, float *acc, int8_t *bits, void *stream) {
     if (!gamma || !b || !loss || !acc || C <= 0) return fail(DEEPIPR_EINVAL, "sign_loss_fwd: bad argument");
+    ProfScope prof(DEEPIPR_K_SIGN_LOSS_FWD, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_sign_loss_fwd, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), gamma, b,
                        alpha, margin, l2, C, loss, acc, bits);
     return check_launch("sign_loss_fwd");
@@ -794,6 +872,7 @@ int deepipr_sign_loss_fwd(const float *gamma, const float *b, float alpha, float
 int deepipr_sign_loss_bwd(const float *dloss, const float *gamma, const float *b, float alpha, float margin,
                           float l2, int C, float *dgamma, void *stream) {
     if (!dloss || !gamma || !b || !dgamma || C <= 0) return fail(DEEPIPR_EINVAL, "sign_loss_bwd: bad argument");
+    ProfScope prof(DEEPIPR_K_SIGN_LOSS_BWD, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_sign_loss_bwd, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), dloss, gamma, b, alpha, margin, l2, C, dgamma);
     return check_launch("sign_loss_bwd");
@@ -830,6 +909,7 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
     double *part = static_cast<double *>(workspace);
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
+    ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
     if (K % 4 == 0 && aligned16(dW) && aligned16(s))
         hipLaunchKernelGGL(k_passport_bwd_finish<true>, dim3(C), dim3(kThreads), 0, st, part, pl.NS, C, gamma, b,
                            alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW);

@@ -34,6 +34,24 @@ extern "C" {
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
 
+/* Opt-in in-situ timing (the one piece of process-global state, off by default): while enabled every
+ * kernel launch below is bracketed by two hipEvents recorded on the launch stream.  read() waits for
+ * the recorded events and returns the accumulated milliseconds / launch count of one kernel since the
+ * last enable(1).  Must be off during hipGraph capture. */
+#define DEEPIPR_K_POOLED_PATCH_MEAN 0
+#define DEEPIPR_K_GAMMA_BETA_FWD 1
+#define DEEPIPR_K_GAMMA_BETA_BWD 2
+#define DEEPIPR_K_AFFINE_FWD 3
+#define DEEPIPR_K_AFFINE_BWD 4
+#define DEEPIPR_K_REDUCE_PARTIALS 5
+#define DEEPIPR_K_PASSPORT_BWD_FINISH 6
+#define DEEPIPR_K_SIGN_LOSS_FWD 7
+#define DEEPIPR_K_SIGN_LOSS_BWD 8
+#define DEEPIPR_K_DKEY 9
+#define DEEPIPR_PROFILE_KERNELS 10
+int deepipr_profile_enable(int on);
+int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
+
 /* ------------------------------------------------------------------ passport conv -> global pool
  * m[k] = mean over (b, oh, ow) of im2col(key)[b, k, (oh,ow)], k = (ci*kh + r)*kw + q, kept in f64,
  * for `nkeys` passport tensors of identical shape laid out back to back.  Because conv and the two
