@@ -34,6 +34,7 @@ constexpr int kThreads = 256;           // 4 wavefronts of 64
 constexpr int kWave = 64;
 constexpr int kMaxGrid = 2048;          // 8 workgroups per CU on 256 CUs
 constexpr int kDkeySplit = 16;
+constexpr int kRowPairMinCo = 256;     // W rows are processed two per workgroup once Co >= 512
 
 thread_local char g_err[512] = "";
 
@@ -60,6 +61,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct ProfState {
     std::mutex mu;
     bool on = false;
+    unsigned long long scopes = 0;
     std::vector<hipEvent_t> pool;
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -90,6 +92,24 @@ struct ProfScope {
         (void)hipEventRecord(b, st);
         std::lock_guard<std::mutex> lk(g_prof.mu);
         g_prof.pending.push_back({k, a, b});
+        // every 4th bracket is followed by an EMPTY one on the same stream: its elapsed time is the
+        // event-pair overhead at this point of the run, which callers subtract (DEEPIPR_K_NULL_BRACKET)
+        if ((++g_prof.scopes & 3) == 0) {
+            hipEvent_t n0 = nullptr, n1 = nullptr;
+            auto take = [&]() {
+                hipEvent_t e;
+                if (!g_prof.pool.empty()) { e = g_prof.pool.back(); g_prof.pool.pop_back(); }
+                else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+                return e;
+            };
+            n0 = take();
+            n1 = take();
+            if (n0 && n1) {
+                (void)hipEventRecord(n0, st);
+                (void)hipEventRecord(n1, st);
+                g_prof.pending.push_back({DEEPIPR_K_NULL_BRACKET, n0, n1});
+            }
+        }
     }
 };
 
@@ -170,81 +190,120 @@ __global__ __launch_bounds__(kThreads) void k_pooled_patch_mean(
 }
 
 // ============================================================================================
-// gamma/beta GEMV: one workgroup per output-channel row of W[Co][K]; W is streamed once with
-// 16 B/lane loads, the two pooled vectors come from L2; f64 FMA accumulation.
+// gamma/beta GEMV: RPW output-channel rows of W[Co][K] per workgroup; W is streamed once with
+// 16 B/lane loads, the two pooled f64 vectors come from L2 and are reused for the RPW rows (they are
+// 4x the bytes of a row, so RPW=2 halves the L2->CU traffic); f64 FMA accumulation.
 // ============================================================================================
-template <bool VEC>
+template <bool VEC, int RPW>
 __global__ __launch_bounds__(kThreads) void k_gamma_beta(
-    const float *__restrict__ W, const double *__restrict__ s, int K,
+    const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
     float *__restrict__ gamma, float *__restrict__ beta) {
-    __shared__ double red[8];
-    const int co = blockIdx.x;
-    const float *row = W + static_cast<size_t>(co) * K;
+    __shared__ double red[8 * RPW];
+    const int co0 = blockIdx.x * RPW;
     const double *ss = s, *sb = s + K;
-    double as = 0.0, ab = 0.0;
+    double as[RPW], ab[RPW];
+    const float *row[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = 0.0;
+        ab[r] = 0.0;
+        row[r] = W + static_cast<size_t>(min(co0 + r, Co - 1)) * K;     // clamp: tail rows recompute the last row
+    }
     if (VEC) {
-        const float4 *row4 = reinterpret_cast<const float4 *>(row);
         const double2 *ss2 = reinterpret_cast<const double2 *>(ss);
         const double2 *sb2 = reinterpret_cast<const double2 *>(sb);
         for (int q = threadIdx.x; q < K / 4; q += kThreads) {
-            const float4 w = row4[q];
+            float4 w[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) w[r] = reinterpret_cast<const float4 *>(row[r])[q];
             const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
             const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
-            as = fma(static_cast<double>(w.x), s0.x, as);
-            as = fma(static_cast<double>(w.y), s0.y, as);
-            as = fma(static_cast<double>(w.z), s1.x, as);
-            as = fma(static_cast<double>(w.w), s1.y, as);
-            ab = fma(static_cast<double>(w.x), b0.x, ab);
-            ab = fma(static_cast<double>(w.y), b0.y, ab);
-            ab = fma(static_cast<double>(w.z), b1.x, ab);
-            ab = fma(static_cast<double>(w.w), b1.y, ab);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                as[r] = fma(static_cast<double>(w[r].x), s0.x, as[r]);
+                as[r] = fma(static_cast<double>(w[r].y), s0.y, as[r]);
+                as[r] = fma(static_cast<double>(w[r].z), s1.x, as[r]);
+                as[r] = fma(static_cast<double>(w[r].w), s1.y, as[r]);
+                ab[r] = fma(static_cast<double>(w[r].x), b0.x, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].y), b0.y, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].z), b1.x, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].w), b1.y, ab[r]);
+            }
         }
     } else {
         for (int k = threadIdx.x; k < K; k += kThreads) {
-            const double w = static_cast<double>(row[k]);
-            as = fma(w, ss[k], as);
-            ab = fma(w, sb[k], ab);
+            const double vs = ss[k], vb = sb[k];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const double w = static_cast<double>(row[r][k]);
+                as[r] = fma(w, vs, as[r]);
+                ab[r] = fma(w, vb, ab[r]);
+            }
         }
     }
-    as = block_sum(as, red);
-    ab = block_sum(ab, red + 4);
-    if (threadIdx.x == 0) {
-        gamma[co] = static_cast<float>(as);
-        beta[co] = static_cast<float>(ab);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = block_sum(as[r], red + 8 * r);
+        ab[r] = block_sum(ab[r], red + 8 * r + 4);
+        if (threadIdx.x == 0 && co0 + r < Co) {
+            gamma[co0 + r] = static_cast<float>(as[r]);
+            beta[co0 + r] = static_cast<float>(ab[r]);
+        }
     }
 }
 
-// Rank-2 update row: dW[co, :] = dg * m_scale + db * m_bias (pooled means rounded to f32).
-template <bool VEC>
-__device__ __forceinline__ void write_dw_row(float *__restrict__ dWrow, const double *__restrict__ s,
-                                             int K, float dg, float db) {
+// Rank-2 update rows: dW[co0+r, :] = dg[r] * m_scale + db[r] * m_bias (pooled means rounded to f32),
+// the pooled vectors loaded once for the RPW rows.
+template <bool VEC, int RPW>
+__device__ __forceinline__ void write_dw_rows(float *__restrict__ dW, const double *__restrict__ s, int Co,
+                                              int K, int co0, const float *dg, const float *db) {
     const double *ss = s, *sb = s + K;
     if (VEC) {
-        float4 *out4 = reinterpret_cast<float4 *>(dWrow);
         const double2 *ss2 = reinterpret_cast<const double2 *>(ss);
         const double2 *sb2 = reinterpret_cast<const double2 *>(sb);
         for (int q = threadIdx.x; q < K / 4; q += kThreads) {
             const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
             const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
-            float4 o;
-            o.x = fmaf(dg, static_cast<float>(s0.x), db * static_cast<float>(b0.x));
-            o.y = fmaf(dg, static_cast<float>(s0.y), db * static_cast<float>(b0.y));
-            o.z = fmaf(dg, static_cast<float>(s1.x), db * static_cast<float>(b1.x));
-            o.w = fmaf(dg, static_cast<float>(s1.y), db * static_cast<float>(b1.y));
-            out4[q] = o;
+            const float4 ms = make_float4(static_cast<float>(s0.x), static_cast<float>(s0.y),
+                                          static_cast<float>(s1.x), static_cast<float>(s1.y));
+            const float4 mb = make_float4(static_cast<float>(b0.x), static_cast<float>(b0.y),
+                                          static_cast<float>(b1.x), static_cast<float>(b1.y));
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                if (co0 + r >= Co) break;
+                float4 o;
+                o.x = fmaf(dg[r], ms.x, db[r] * mb.x);
+                o.y = fmaf(dg[r], ms.y, db[r] * mb.y);
+                o.z = fmaf(dg[r], ms.z, db[r] * mb.z);
+                o.w = fmaf(dg[r], ms.w, db[r] * mb.w);
+                reinterpret_cast<float4 *>(dW + static_cast<size_t>(co0 + r) * K)[q] = o;
+            }
         }
     } else {
-        for (int k = threadIdx.x; k < K; k += kThreads)
-            dWrow[k] = fmaf(dg, static_cast<float>(ss[k]), db * static_cast<float>(sb[k]));
+        for (int k = threadIdx.x; k < K; k += kThreads) {
+            const float ms = static_cast<float>(ss[k]), mb = static_cast<float>(sb[k]);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                if (co0 + r >= Co) break;
+                dW[static_cast<size_t>(co0 + r) * K + k] = fmaf(dg[r], ms, db[r] * mb);
+            }
+        }
     }
 }
 
-template <bool VEC>
+template <bool VEC, int RPW>
 __global__ __launch_bounds__(kThreads) void k_gamma_beta_bwd(
     const float *__restrict__ dgamma, const float *__restrict__ dbeta, const double *__restrict__ s,
-    int K, float *__restrict__ dW) {
-    const int co = blockIdx.x;
-    write_dw_row<VEC>(dW + static_cast<size_t>(co) * K, s, K, dgamma[co], dbeta[co]);
+    int Co, int K, float *__restrict__ dW) {
+    const int co0 = blockIdx.x * RPW;
+    float dg[RPW], db[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int co = min(co0 + r, Co - 1);
+        dg[r] = dgamma[co];
+        db[r] = dbeta[co];
+    }
+    write_dw_rows<VEC, RPW>(dW, s, Co, K, co0, dg, db);
 }
 
 // ============================================================================================
@@ -374,17 +433,26 @@ __global__ __launch_bounds__(kThreads) void k_affine_fwd_v4(
         }
     }
     const unsigned step = nblk * kThreads;
-    for (unsigned q = blockIdx.x * kThreads + threadIdx.x; q < n4; q += step) {
+    unsigned q = blockIdx.x * kThreads + threadIdx.x;
+    // two independent float4s per trip: both loads are in flight before either is consumed
+    for (; q + step < n4; q += 2 * step) {
+        const unsigned q1 = q + step;
+        const float4 v0 = x[q], v1 = x[q1];
+        const unsigned p0 = fdiv(q, p4div), p1 = fdiv(q1, p4div);
+        const unsigned c0 = p0 - fdiv(p0, cdiv) * C, c1 = p1 - fdiv(p1, cdiv) * C;
+        const float g0 = gamma[c0], t0 = beta[c0], g1 = gamma[c1], t1 = beta[c1];
+        y[q] = make_float4(affine1<RELU>(v0.x, g0, t0), affine1<RELU>(v0.y, g0, t0),
+                           affine1<RELU>(v0.z, g0, t0), affine1<RELU>(v0.w, g0, t0));
+        y[q1] = make_float4(affine1<RELU>(v1.x, g1, t1), affine1<RELU>(v1.y, g1, t1),
+                            affine1<RELU>(v1.z, g1, t1), affine1<RELU>(v1.w, g1, t1));
+    }
+    if (q < n4) {
         const unsigned plane = fdiv(q, p4div);
         const unsigned c = plane - fdiv(plane, cdiv) * C;
         const float g = gamma[c], bt = beta[c];
         const float4 v = x[q];
-        float4 o;
-        o.x = affine1<RELU>(v.x, g, bt);
-        o.y = affine1<RELU>(v.y, g, bt);
-        o.z = affine1<RELU>(v.z, g, bt);
-        o.w = affine1<RELU>(v.w, g, bt);
-        y[q] = o;
+        y[q] = make_float4(affine1<RELU>(v.x, g, bt), affine1<RELU>(v.y, g, bt), affine1<RELU>(v.z, g, bt),
+                           affine1<RELU>(v.w, g, bt));
     }
 }
 
@@ -493,23 +561,37 @@ __global__ __launch_bounds__(kThreads) void k_affine_bwd_small(
     const int u = t - r * pl.row_u;              // unit inside the row
     const bool lane_on = (r < pl.npi) && (u * VEC < ct * P);
 
+    // element i of this thread's unit: channel cc[i] of the tile, position e[i] in its plane; the LDS
+    // slot (cc*npi + r)*P + e keeps every channel's partial sums contiguous for the combine below
     float g[VEC], bt[VEC], a_gx[VEC], a_g[VEC];
+    int slot[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         a_gx[i] = 0.0f;
         a_g[i] = 0.0f;
-        const int c = lane_on ? c0 + (u * VEC + i) / P : c0;
-        g[i] = gamma[c];
-        bt[i] = beta[c];
+        const int er = u * VEC + i;
+        const int cc = lane_on ? er / P : 0;
+        slot[i] = (cc * pl.npi + r) * P + (er - cc * P);
+        g[i] = gamma[c0 + cc];
+        bt[i] = beta[c0 + cc];
     }
     if (lane_on) {
         const int it0 = blockIdx.y * pl.ips, it1 = min(pl.iters, it0 + pl.ips);
-        for (int it = it0; it < it1; ++it) {
-            const int n = it * pl.npi + r;
-            if (n >= N) break;
-            const size_t off = (static_cast<size_t>(n) * C + c0) * P + static_cast<size_t>(u) * VEC;
-            const U vdy = *reinterpret_cast<const U *>(dy + off);
-            const U vxh = *reinterpret_cast<const U *>(xh + off);
+        const size_t img = static_cast<size_t>(C) * P;
+        size_t off = (static_cast<size_t>(it0 * pl.npi + r) * C + c0) * P + static_cast<size_t>(u) * VEC;
+        const size_t hop = img * pl.npi;
+        int n = it0 * pl.npi + r;
+        U vdy{}, vxh{};
+        if (n < N) {
+            vdy = *reinterpret_cast<const U *>(dy + off);
+            vxh = *reinterpret_cast<const U *>(xh + off);
+        }
+        for (int it = it0; it < it1 && n < N; ++it, n += pl.npi, off += hop) {
+            U ndy{}, nxh{};
+            if (it + 1 < it1 && n + pl.npi < N) {            // next image's loads fly during this one's math
+                ndy = *reinterpret_cast<const U *>(dy + off + hop);
+                nxh = *reinterpret_cast<const U *>(xh + off + hop);
+            }
             float d[VEC], x[VEC], o[VEC];
             Unit<VEC>::get(vdy, d);
             Unit<VEC>::get(vxh, x);
@@ -522,28 +604,27 @@ __global__ __launch_bounds__(kThreads) void k_affine_bwd_small(
                 a_g[i] += dz;
             }
             *reinterpret_cast<U *>(dx + off) = Unit<VEC>::make(o);
+            vdy = ndy;
+            vxh = nxh;
         }
     }
-    // stage the per-thread sums: slot (r, element e of the row) = r*row_u*VEC + u*VEC + i
-    if (r < pl.npi) {
+    if (lane_on) {        // slots of channels beyond a partial tile are never read
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            sacc[0][t * VEC + i] = a_gx[i];
-            sacc[1][t * VEC + i] = a_g[i];
+            sacc[0][slot[i]] = a_gx[i];
+            sacc[1][slot[i]] = a_g[i];
         }
     }
     __syncthreads();
-    // one wavefront per channel: fixed-order strided sum over its npi*P slots, f64 butterfly
+    // one wavefront per channel: all 64 lanes stride over its npi*P contiguous slots, f64 butterfly
     const int wave = t >> 6, lane = t & 63;
-    const int row_f = pl.row_u * VEC;
+    const int cnt = pl.npi * P;
     for (int cc = wave; cc < ct; cc += kThreads / kWave) {
+        const float *p0 = sacc[0] + cc * cnt, *p1 = sacc[1] + cc * cnt;
         double sgx = 0.0, sg = 0.0;
-        for (int rr = 0; rr < pl.npi; ++rr) {
-            const int base = rr * row_f + cc * P;
-            for (int e = lane; e < P; e += kWave) {
-                sgx += static_cast<double>(sacc[0][base + e]);
-                sg += static_cast<double>(sacc[1][base + e]);
-            }
+        for (int e = lane; e < cnt; e += kWave) {
+            sgx += static_cast<double>(p0[e]);
+            sg += static_cast<double>(p1[e]);
         }
         sgx = wave_sum(sgx);
         sg = wave_sum(sg);
@@ -608,39 +689,43 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(
     (which == 0 ? dgamma : dbeta)[c] = static_cast<float>(acc);
 }
 
-// Fused finish of a passport layer's backward: one workgroup per output channel co.
+// Fused finish of a passport layer's backward: RPW output channels per workgroup.
 //   dgamma[co] = sum_split part + dgamma_extra[co] + dloss * d(sign loss)/dgamma ;  dbeta likewise
 //   dW[co, :]  = dgamma[co] * m_scale + dbeta[co] * m_bias
-template <bool VEC>
+// Every wavefront finishes the (few) partial sums itself -- identical fixed-order arithmetic in all four,
+// so no LDS hand-off or barrier delays the dW stores.
+template <bool VEC, int RPW>
 __global__ __launch_bounds__(kThreads) void k_passport_bwd_finish(
     const double *__restrict__ part, int NS, int C, const float *__restrict__ gamma,
     const float *__restrict__ b, float alpha, float margin, float l2, const float *__restrict__ dloss,
     const float *__restrict__ dgamma_extra, const float *__restrict__ dbeta_extra,
     const double *__restrict__ s, int K, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ dW) {
-    __shared__ float sh[2];
-    const int co = blockIdx.x;
-    if (threadIdx.x < kWave) {                         // wavefront 0 finishes the two scalars
+    const int co0 = blockIdx.x * RPW;
+    const int lane = threadIdx.x & 63;
+    float dgv[RPW], dbv[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int co = min(co0 + r, C - 1);
         double ag = 0.0, ab = 0.0;
-        for (int sp = threadIdx.x; sp < NS; sp += kWave) {
+        for (int sp = lane; sp < NS; sp += kWave) {
             ag += part[(static_cast<size_t>(sp) * 2 + 0) * C + co];
             ab += part[(static_cast<size_t>(sp) * 2 + 1) * C + co];
         }
         ag = wave_sum(ag);
         ab = wave_sum(ab);
-        if (threadIdx.x == 0) {
-            float dg = static_cast<float>(ag), db = static_cast<float>(ab);
-            if (dgamma_extra) dg += dgamma_extra[co];
-            if (dbeta_extra) db += dbeta_extra[co];
-            if (dloss) dg += dloss[0] * sign_loss_grad1(gamma[co], b[co], alpha, margin, l2);
+        float dg = static_cast<float>(ag), db = static_cast<float>(ab);
+        if (dgamma_extra) dg += dgamma_extra[co];
+        if (dbeta_extra) db += dbeta_extra[co];
+        if (dloss) dg += dloss[0] * sign_loss_grad1(gamma[co], b[co], alpha, margin, l2);
+        dgv[r] = dg;
+        dbv[r] = db;
+        if (threadIdx.x == 0 && co0 + r < C) {
             dgamma[co] = dg;
             dbeta[co] = db;
-            sh[0] = dg;
-            sh[1] = db;
         }
     }
-    __syncthreads();
-    write_dw_row<VEC>(dW + static_cast<size_t>(co) * K, s, K, sh[0], sh[1]);
+    write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,10 +871,15 @@ int deepipr_gamma_beta_fwd(const float *W, const double *s, int Co, int K, float
     if (!W || !s || !gamma || !beta || Co <= 0 || K <= 0) return fail(DEEPIPR_EINVAL, "gamma_beta_fwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
-    if (K % 4 == 0 && aligned16(W) && aligned16(s))
-        hipLaunchKernelGGL(k_gamma_beta<true>, dim3(Co), dim3(kThreads), 0, st, W, s, K, gamma, beta);
-    else
-        hipLaunchKernelGGL(k_gamma_beta<false>, dim3(Co), dim3(kThreads), 0, st, W, s, K, gamma, beta);
+    const bool vec = K % 4 == 0 && aligned16(W) && aligned16(s);
+    if (Co >= 2 * kRowPairMinCo) {               // enough rows to fill the chip with two per workgroup
+        const dim3 grid((Co + 1) / 2);
+        if (vec) hipLaunchKernelGGL((k_gamma_beta<true, 2>), grid, dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+        else hipLaunchKernelGGL((k_gamma_beta<false, 2>), grid, dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_gamma_beta<true, 1>), dim3(Co), dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+        else hipLaunchKernelGGL((k_gamma_beta<false, 1>), dim3(Co), dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+    }
     return check_launch("gamma_beta_fwd");
 }
 
@@ -799,10 +889,15 @@ int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double
         return fail(DEEPIPR_EINVAL, "gamma_beta_bwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
-    if (K % 4 == 0 && aligned16(dW) && aligned16(s))
-        hipLaunchKernelGGL(k_gamma_beta_bwd<true>, dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, K, dW);
-    else
-        hipLaunchKernelGGL(k_gamma_beta_bwd<false>, dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, K, dW);
+    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
+    if (Co >= 2 * kRowPairMinCo) {
+        const dim3 grid((Co + 1) / 2);
+        if (vec) hipLaunchKernelGGL((k_gamma_beta_bwd<true, 2>), grid, dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+        else hipLaunchKernelGGL((k_gamma_beta_bwd<false, 2>), grid, dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_gamma_beta_bwd<true, 1>), dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+        else hipLaunchKernelGGL((k_gamma_beta_bwd<false, 1>), dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+    }
     return check_launch("gamma_beta_bwd");
 }
 
@@ -910,12 +1005,17 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
     ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
-    if (K % 4 == 0 && aligned16(dW) && aligned16(s))
-        hipLaunchKernelGGL(k_passport_bwd_finish<true>, dim3(C), dim3(kThreads), 0, st, part, pl.NS, C, gamma, b,
-                           alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW);
-    else
-        hipLaunchKernelGGL(k_passport_bwd_finish<false>, dim3(C), dim3(kThreads), 0, st, part, pl.NS, C, gamma, b,
-                           alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW);
+    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
+#define DEEPIPR_FINISH_ARGS part, pl.NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW
+    if (C >= 2 * kRowPairMinCo) {
+        const dim3 grid((C + 1) / 2);
+        if (vec) hipLaunchKernelGGL((k_passport_bwd_finish<true, 2>), grid, dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+        else hipLaunchKernelGGL((k_passport_bwd_finish<false, 2>), grid, dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_passport_bwd_finish<true, 1>), dim3(C), dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+        else hipLaunchKernelGGL((k_passport_bwd_finish<false, 1>), dim3(C), dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+    }
+#undef DEEPIPR_FINISH_ARGS
     return check_launch("passport_bwd(finish)");
 }
 

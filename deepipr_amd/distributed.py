@@ -60,6 +60,11 @@ def broadcast_state(model, src=0):
                 continue
             seen.add(t.data_ptr())
             dist.broadcast(t, src)
+    # c10d writes into the key tensors without bumping their autograd version counter, which is what the
+    # pooled-passport cache keys on: drop the cached pooled means explicitly.
+    for m in model.modules():
+        if isinstance(m, PASSPORT_TYPES):
+            m.invalidate_key_cache()
 
 
 def replicate(model, device, bucket_mb=BUCKET_MB):

@@ -126,6 +126,11 @@ class PassportLayerBase(nn.Module):
     def _sign(self):
         return getattr(self, self.SIGN)
 
+    def invalidate_key_cache(self):
+        """Forget the cached pooled passport means.  Needed only after the key tensors were modified in place
+        by something that does not bump their version counter (e.g. a c10d broadcast)."""
+        self._pooled.clear()
+
     def _geometry(self):
         c = self.conv
         if c.groups != 1 or tuple(c.dilation) != (1, 1) or c.stride[0] != c.stride[1] or c.padding[0] != c.padding[1]:

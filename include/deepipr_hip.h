@@ -48,7 +48,8 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_SIGN_LOSS_FWD 7
 #define DEEPIPR_K_SIGN_LOSS_BWD 8
 #define DEEPIPR_K_DKEY 9
-#define DEEPIPR_PROFILE_KERNELS 10
+#define DEEPIPR_K_NULL_BRACKET 10   /* empty event pair recorded after every 4th launch: bracket overhead */
+#define DEEPIPR_PROFILE_KERNELS 11
 int deepipr_profile_enable(int on);
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 

@@ -1,0 +1,126 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes drive the product's replicate() / trainers.
+
+The HIP kernels cannot run here, so each worker monkeypatches passport_ops.kernels with the oracle-backed
+stand-in (tests/oracle_kernels.py); everything else -- key materialisation check, rank-0 state broadcast,
+DistributedDataParallel wrapping, the V1 and V2 (DualBranch) steps -- is the shipped code.
+
+Checked: (1) replicas start identical to rank 0 (weights, keys, signature bits) although every rank was
+built with a different seed; (2) one data-parallel step on two half-batches equals one single-process step
+on the full batch (norm_type='none', so no per-shard batch statistics enter); (3) ranks stay in lock step.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build(private, seed):
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.alexnet_passport import AlexNetPassport
+    from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+    from oracle.cases import alexnet_config
+    kw = construct_passport_kwargs_from_dict({'passport_config': alexnet_config(), 'norm_type': 'none',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = (AlexNetPassportPrivate if private else AlexNetPassport)(3, 10, kw)
+    model.train()
+    with torch.no_grad():
+        model(torch.randn(2, 3, 32, 32))          # materialise the random keys (rank-dependent on purpose)
+    return model
+
+
+def _batch():
+    g = torch.Generator().manual_seed(77)
+    return torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+
+
+def _worker(rank, world, port, private, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from deepipr_amd import distributed as D
+    from deepipr_amd import passport_ops
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from tests.oracle_kernels import OracleKernels
+    passport_ops.kernels = OracleKernels()
+    r, lr, w = D.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    model = _build(private, seed=100 + rank)       # different weights / keys / bits per rank before the sync
+    dev = torch.device('cpu')
+    wrapped = D.replicate(DualBranch(model) if private else model, dev)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    x, y = _batch()
+    lo, hi = rank * 4, rank * 4 + 4
+    step = train_step_v23 if private else train_step_v1
+    out = step(wrapped, opt, x[lo:hi], y[lo:hi])
+    torch.save({'state0': state0, 'state1': {k: v.clone() for k, v in model.state_dict().items()},
+                'sign_loss': float(out[1])}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('private', [False, True])
+def test_two_rank_step_equals_single_process_step(private, tmp_path, monkeypatch):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, private, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    # (1) after replicate(): every rank holds rank 0's weights, keys and signature bits
+    for k in r0['state0']:
+        assert torch.equal(r0['state0'][k], r1['state0'][k]), k
+    assert any(k.endswith('key') or k.endswith('key_private') for k in r0['state0'])
+    # (3) ranks stay identical after the step
+    for k in r0['state1']:
+        assert torch.equal(r0['state1'][k], r1['state1'][k]), k
+    assert r0['sign_loss'] == pytest.approx(r1['sign_loss'], rel=1e-6)
+
+    # (2) the same step in one process on the full batch, starting from rank 0's synchronised state
+    from deepipr_amd import passport_ops
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from tests.oracle_kernels import OracleKernels
+    monkeypatch.setattr(passport_ops, 'kernels', OracleKernels())
+    torch.set_num_threads(4)
+    model = _build(private, seed=5)
+    model.load_state_dict(r0['state0'])
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    x, y = _batch()
+    if private:
+        out = train_step_v23(DualBranch(model), opt, x, y)
+    else:
+        out = train_step_v1(model, opt, x, y)
+    assert float(out[1]) == pytest.approx(r0['sign_loss'], rel=1e-5)
+    single = model.state_dict()
+    for k, v in r0['state1'].items():
+        if v.dtype.is_floating_point:
+            assert torch.allclose(single[k], v, rtol=1e-4, atol=1e-6), (k, float((single[k] - v).abs().max()))
+
+
+def test_replicate_refuses_unset_keys():
+    from deepipr_amd import distributed as D
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.alexnet_passport import AlexNetPassport
+    from oracle.cases import alexnet_config
+    kw = construct_passport_kwargs_from_dict({'passport_config': alexnet_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    with pytest.raises(RuntimeError, match='passport keys'):
+        D.check_keys_materialised(AlexNetPassport(3, 10, kw))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace CSV over the steady-state steps only.
+
+MIOpen's find mode (cudnn.benchmark) and the warm-up pollute whole-process statistics, so the window is
+cut by a once-per-step kernel: it spans the last `--steps` occurrences of the cross-entropy forward
+kernel (nll_loss_forward*), i.e. exactly that many full train steps.
+
+    python tools/trace_summary.py <kernel_trace.csv> --steps 20 [--top 25] > profiles/<name>.md
+"""
+import argparse
+import csv
+import collections
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('csv')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--top', type=int, default=25)
+    ap.add_argument('--marker', default='nll_loss_forward')
+    args = ap.parse_args()
+    rows = []
+    with open(args.csv) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if args.marker in r[2]]
+    if len(marks) <= args.steps:
+        raise SystemExit('only %d marker kernels in the trace' % len(marks))
+    lo, hi = marks[-args.steps - 1], marks[-1]
+    win = rows[lo:hi]
+    wall = rows[hi][0] - rows[lo][0]
+    stats = collections.defaultdict(list)
+    for s, e, n in win:
+        stats[n].append(e - s)
+    busy = sum(sum(v) for v in stats.values())
+    print('# steady-state kernel summary: %d steps, %d dispatches (%.1f per step)' %
+          (args.steps, len(win), len(win) / args.steps))
+    print('wall per step %.3f ms, GPU busy per step %.3f ms (%.1f %% of wall)\n' %
+          (wall / args.steps / 1e6, busy / args.steps / 1e6, 100.0 * busy / wall))
+    print('| kernel | calls/step | avg us | min us | max us | us/step | % busy |')
+    print('|---|---|---|---|---|---|---|')
+    order = sorted(stats.items(), key=lambda kv: -sum(kv[1]))
+    shown = 0
+    for n, v in order:
+        mine = '(anonymous namespace)::k_' in n
+        if shown >= args.top and not mine:
+            continue
+        shown += 1
+        short = n.replace('void ', '').replace('(anonymous namespace)::', '')
+        short = short[:90]
+        print('| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.2f |' %
+              (short, len(v) / args.steps, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3,
+               sum(v) / args.steps / 1e3, 100.0 * sum(v) / busy))
+
+
+if __name__ == '__main__':
+    main()
