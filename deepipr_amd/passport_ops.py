@@ -41,6 +41,27 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+class _on:
+    """Make `dev` the current HIP device for a launch; a no-op (one integer compare) in the normal
+    one-process-per-GPU setting where it already is."""
+    __slots__ = ('dev', 'prev')
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.prev = None
+
+    def __enter__(self):
+        idx = self.dev.index
+        if idx is not None and torch.cuda.current_device() != idx:
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -53,7 +74,7 @@ class HipKernels:
         dev = _chk(keys)
         nk, b, ci, h, w = keys.shape
         m = torch.empty((nk, ci * kh * kw), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_pooled_patch_mean(_p(keys), nk, b, ci, h, w, kh, kw, stride, pad, _p(m),
                                                            _stream(dev)), 'pooled_patch_mean')
         return m
@@ -63,7 +84,7 @@ class HipKernels:
         co = weight.shape[0]
         k = weight.numel() // co
         gb = torch.empty((2, co), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_gamma_beta_fwd(_p(weight), _p(m), co, k, _p(gb[0]), _p(gb[1]),
                                                         _stream(dev)), 'gamma_beta_fwd')
         return gb[0], gb[1]
@@ -72,7 +93,7 @@ class HipKernels:
         dev = _chk(dgamma, dbeta, m)
         co = wshape[0]
         dw = torch.empty(wshape, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_gamma_beta_bwd(_p(dgamma), _p(dbeta), _p(m), co, dw.numel() // co, _p(dw),
                                                         _stream(dev)), 'gamma_beta_bwd')
         return dw
@@ -84,7 +105,7 @@ class HipKernels:
         lib = _lib.lib()
         ws = torch.empty(lib.deepipr_gamma_beta_dkey_workspace_bytes(ci, kh, kw), dtype=torch.uint8, device=dev)
         dkeys = torch.empty((2, b, ci, h, w), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.deepipr_gamma_beta_dkey(_p(dgamma), _p(dbeta), _p(weight), co, b, ci, h, w, kh, kw,
                                                   stride, pad, _p(dkeys), _p(ws), _stream(dev)), 'gamma_beta_dkey')
         return dkeys[0], dkeys[1]
@@ -93,7 +114,7 @@ class HipKernels:
         dev = _chk(xhat, gamma, beta)
         n, c = xhat.shape[0], xhat.shape[1]
         y = torch.empty_like(xhat)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_affine_relu_fwd(_p(xhat), _p(gamma), _p(beta), _p(y), n, c,
                                                          xhat.numel() // (n * c), int(relu), _stream(dev)),
                        'affine_relu_fwd')
@@ -107,7 +128,7 @@ class HipKernels:
         ws = torch.empty(lib.deepipr_affine_relu_bwd_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
         dx = torch.empty_like(xhat)
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.deepipr_affine_relu_bwd(_p(dy), _p(xhat), _p(gamma), _p(beta), _p(dx), _p(dgb[0]),
                                                   _p(dgb[1]), n, c, hw, int(relu), _p(ws), _stream(dev)),
                        'affine_relu_bwd')
@@ -118,7 +139,7 @@ class HipKernels:
         c = gamma.numel()
         out = torch.empty(2, dtype=torch.float32, device=dev)
         bits = torch.empty(c, dtype=torch.int8, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_sign_loss_fwd(_p(gamma), _p(b), alpha, margin, l2, c, _p(out[0]),
                                                        _p(out[1]), _p(bits), _stream(dev)), 'sign_loss_fwd')
         return out[0], out[1], bits
@@ -126,7 +147,7 @@ class HipKernels:
     def sign_loss_bwd(self, dloss, gamma, b, alpha, margin=MARGIN, l2=L2):
         dev = _chk(dloss, gamma, b)
         dg = torch.empty_like(gamma)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_sign_loss_bwd(_p(dloss), _p(gamma), _p(b), alpha, margin, l2,
                                                        gamma.numel(), _p(dg), _stream(dev)), 'sign_loss_bwd')
         return dg
@@ -143,7 +164,7 @@ class HipKernels:
         if b is not None:
             sl = torch.empty(2, dtype=torch.float32, device=dev)
             bits = torch.empty(c, dtype=torch.int8, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().deepipr_passport_fwd(
                 _p(xhat), _p(weight), _p(m), _p(b), alpha, margin, l2, n, c, hw, k, int(relu), _p(y), _p(gb[0]),
                 _p(gb[1]), _p(sl[0]) if sl is not None else None, _p(sl[1]) if sl is not None else None, _p(bits),
@@ -163,7 +184,7 @@ class HipKernels:
         dx = torch.empty_like(xhat)
         dw = torch.empty(wshape, dtype=torch.float32, device=dev)
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.deepipr_passport_bwd(
                 _p(dy), _p(xhat), _p(gamma), _p(beta), _p(m), _p(b), alpha, margin, l2, _p(dloss),
                 _p(dgamma_extra), _p(dbeta_extra), n, c, hw, dw.numel() // c, int(relu), _p(dx), _p(dw),

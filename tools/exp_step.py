@@ -58,7 +58,7 @@ def main():
         model.train()
         with torch.no_grad():
             model(xs[0])
-        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, capturable=False)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
         sx, sy = xs[0].clone(), ys[0].clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
