@@ -43,6 +43,13 @@ SIGNATURES = {
     'deepipr_passport_bwd_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p,
                                     _f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp, _vp]),
+    'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
+    'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
+                                       _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,
+                                       _f32p, _f32p, _i8p, _vp, _vp]),
+    'deepipr_passport_bn_bwd': (_int, [_f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _f32p,
+                                       _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _vp,
+                                       _vp]),
 }
 ABI_VERSION = 1
 
@@ -88,7 +95,8 @@ def check(rc, what):
 
 
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
-                   'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'null_bracket']
+                   'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
+                   'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd']
 
 
 def profile_enable(on):

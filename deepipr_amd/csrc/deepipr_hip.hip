@@ -19,6 +19,7 @@
 //   * 16 B per lane (float4) global accesses wherever the plane size allows; grids are sized to
 //     >= 4 workgroups per CU (256 CUs) and capped at 2048 with grid-stride loops.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -55,13 +56,12 @@ int check_launch(const char *what) {
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------------------------------------
-// Opt-in in-situ kernel timing (deepipr_profile_*): when enabled, every launch is bracketed by two
-// hipEvents recorded on the launch stream; durations are read back later with deepipr_profile_read.
-// Off by default (one relaxed bool load per launch); must stay off during hipGraph capture.
+// Opt-in in-situ kernel timing (deepipr_profile_*): when enabled, every kernel is dispatched with a
+// start and a stop hipEvent attached to its own dispatch packet; durations are read back later with
+// deepipr_profile_read.  Off by default (one bool load per launch); must stay off during hipGraph capture.
 struct ProfState {
     std::mutex mu;
     bool on = false;
-    unsigned long long scopes = 0;
     std::vector<hipEvent_t> pool;
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -72,9 +72,9 @@ ProfState g_prof;
 
 struct ProfScope {
     int k;
-    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(int kernel, hipStream_t stream) : k(kernel), st(stream) {
+    bool used = false;
+    ProfScope(int kernel, hipStream_t) : k(kernel) {
         if (!g_prof.on) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         auto take = [&]() {
@@ -85,33 +85,28 @@ struct ProfScope {
         };
         a = take();
         b = take();
-        if (a && b) (void)hipEventRecord(a, st);
+        if (!a || !b) a = b = nullptr;
     }
     ~ProfScope() {
-        if (!a || !b) return;
-        (void)hipEventRecord(b, st);
+        if (!a) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        g_prof.pending.push_back({k, a, b});
-        // every 4th bracket is followed by an EMPTY one on the same stream: its elapsed time is the
-        // event-pair overhead at this point of the run, which callers subtract (DEEPIPR_K_NULL_BRACKET)
-        if ((++g_prof.scopes & 3) == 0) {
-            hipEvent_t n0 = nullptr, n1 = nullptr;
-            auto take = [&]() {
-                hipEvent_t e;
-                if (!g_prof.pool.empty()) { e = g_prof.pool.back(); g_prof.pool.pop_back(); }
-                else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
-                return e;
-            };
-            n0 = take();
-            n1 = take();
-            if (n0 && n1) {
-                (void)hipEventRecord(n0, st);
-                (void)hipEventRecord(n1, st);
-                g_prof.pending.push_back({DEEPIPR_K_NULL_BRACKET, n0, n1});
-            }
-        }
+        if (used) g_prof.pending.push_back({k, a, b});
+        else { g_prof.pool.push_back(a); g_prof.pool.push_back(b); }
     }
 };
+
+// Launch `kernel`; when timing is on, the FIRST launch of the scope carries the scope's two events as the
+// dispatch's own start/stop events (hipExtLaunchKernelGGL): their elapsed time is the kernel's execution time,
+// the same quantity rocprofv3's kernel trace reports, with no event-record overhead in it.
+#define DEEPIPR_LAUNCH(prof, kernel, grid, block, st, ...)                                              \
+    do {                                                                                                \
+        if ((prof).a && !(prof).used) {                                                                 \
+            (prof).used = true;                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, st, (prof).a, (prof).b, 0, __VA_ARGS__);      \
+        } else {                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                \
+        }                                                                                               \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // Exact unsigned division by a launch-time constant (n < 2^31): q = (n * M) >> S.
@@ -728,6 +723,445 @@ __global__ __launch_bounds__(kThreads) void k_passport_bwd_finish(
     write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);
 }
 
+
+// ============================================================================================
+// BatchNorm(affine=False, models/layers/passportconv2d.py:58) fused into the passport layer.
+//
+//   forward :  k_bn_walk<STATS>   per-(split,channel) sums of x, x^2                      (4 B/elt)
+//              k_gamma_beta       + finish: mean / invstd / running stats -> channel table
+//              k_bn_affine_fwd    y = relu(gamma*((x-mean)*invstd) + beta)               (8 B/elt)
+//   backward:  k_bn_walk<BWD>     sums of dz*xhat, dz   (dz = dy masked by the recomputed ReLU) (8 B/elt)
+//              k_passport_bwd_finish  dgamma, dbeta, dW + table entries c2 = sum(dz)/M, c3 = sum(dz*xhat)/M
+//              k_bn_affine_bwd    dx = gamma*invstd*(dz - c2 - xhat*c3)                  (12 B/elt)
+//
+// The normalised activation xhat is never materialised; x (the conv output) is the only saved
+// activation.  Channel table: tbl[c][8] = {mean, invstd, gamma, beta, c2, c3, -, -}.
+// ============================================================================================
+constexpr int kTbl = 8;
+enum WalkMode { WALK_STATS = 1, WALK_BN_BWD = 2 };
+
+struct BnFinishArgs {
+    const double *part;        // [NS][2][C] sums of x and x^2 (training) or nullptr (use running stats)
+    int NS;
+    double inv_m;              // 1 / (N*HW)
+    double unbias;             // M / (M-1)
+    float eps, momentum;
+    float *running_mean, *running_var;   // may be nullptr
+    long long *num_batches_tracked;      // may be nullptr
+    float *tbl;                // [C][8]
+};
+
+// All 64 lanes of one wavefront call this for channel c; lane 0 writes.
+__device__ __forceinline__ void bn_finish_channel(const BnFinishArgs &f, int C, int c, float gamma, float beta,
+                                                  int lane) {
+    float mean, invstd;
+    if (f.part) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int sp = lane; sp < f.NS; sp += kWave) {
+            s1 += f.part[(static_cast<size_t>(sp) * 2 + 0) * C + c];
+            s2 += f.part[(static_cast<size_t>(sp) * 2 + 1) * C + c];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const double mu = s1 * f.inv_m;
+        double var = s2 * f.inv_m - mu * mu;           // biased variance, f64
+        if (var < 0.0) var = 0.0;
+        mean = static_cast<float>(mu);
+        invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
+        if (lane == 0 && f.running_mean) {
+            f.running_mean[c] = (1.0f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+            f.running_var[c] = (1.0f - f.momentum) * f.running_var[c] +
+                               f.momentum * static_cast<float>(var * f.unbias);
+        }
+    } else {                                            // evaluation: running statistics
+        mean = f.running_mean[c];
+        invstd = static_cast<float>(1.0 / sqrt(static_cast<double>(f.running_var[c]) + static_cast<double>(f.eps)));
+    }
+    if (lane == 0) {
+        float4 *t = reinterpret_cast<float4 *>(f.tbl + static_cast<size_t>(c) * kTbl);
+        t[0] = make_float4(mean, invstd, gamma, beta);
+        t[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// gamma/beta GEMV + BN finish for the same rows (one launch between the stats pass and the apply pass).
+template <bool VEC, int RPW>
+__global__ __launch_bounds__(kThreads) void k_gamma_beta_bn(
+    const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
+    float *__restrict__ gamma, float *__restrict__ beta, BnFinishArgs f) {
+    __shared__ double red[8 * RPW];
+    const int co0 = blockIdx.x * RPW;
+    const double *ss = s, *sb = s + K;
+    double as[RPW], ab[RPW];
+    const float *row[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = 0.0;
+        ab[r] = 0.0;
+        row[r] = W + static_cast<size_t>(min(co0 + r, Co - 1)) * K;
+    }
+    if (VEC) {
+        const double2 *ss2 = reinterpret_cast<const double2 *>(ss);
+        const double2 *sb2 = reinterpret_cast<const double2 *>(sb);
+        for (int q = threadIdx.x; q < K / 4; q += kThreads) {
+            float4 w[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) w[r] = reinterpret_cast<const float4 *>(row[r])[q];
+            const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
+            const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                as[r] = fma(static_cast<double>(w[r].x), s0.x, as[r]);
+                as[r] = fma(static_cast<double>(w[r].y), s0.y, as[r]);
+                as[r] = fma(static_cast<double>(w[r].z), s1.x, as[r]);
+                as[r] = fma(static_cast<double>(w[r].w), s1.y, as[r]);
+                ab[r] = fma(static_cast<double>(w[r].x), b0.x, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].y), b0.y, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].z), b1.x, ab[r]);
+                ab[r] = fma(static_cast<double>(w[r].w), b1.y, ab[r]);
+            }
+        }
+    } else {
+        for (int k = threadIdx.x; k < K; k += kThreads) {
+            const double vs = ss[k], vb = sb[k];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const double w = static_cast<double>(row[r][k]);
+                as[r] = fma(w, vs, as[r]);
+                ab[r] = fma(w, vb, ab[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = block_sum(as[r], red + 8 * r);
+        ab[r] = block_sum(ab[r], red + 8 * r + 4);
+        if (co0 + r < Co) {
+            const float g = static_cast<float>(as[r]), bt = static_cast<float>(ab[r]);
+            if (threadIdx.x == 0) {
+                gamma[co0 + r] = g;
+                beta[co0 + r] = bt;
+            }
+            if (threadIdx.x < kWave) bn_finish_channel(f, Co, co0 + r, g, bt, threadIdx.x);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.part && f.num_batches_tracked) *f.num_batches_tracked += 1;
+}
+
+// Public branch (learnable gamma/beta given): table only, one wavefront per channel.
+__global__ __launch_bounds__(kThreads) void k_bn_table(const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, int C, BnFinishArgs f) {
+    const int c = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+    if (c < C) bn_finish_channel(f, C, c, gamma[c], beta[c], threadIdx.x & 63);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.part && f.num_batches_tracked) *f.num_batches_tracked += 1;
+}
+
+// ---- channel-walk reduction passes (same tiling as k_affine_bwd_*, nothing written but the partials) ----
+template <int MODE, bool RELU>
+__device__ __forceinline__ void walk_accum(float d, float x, float mean, float invstd, float g, float bt,
+                                           float &a0, float &a1) {
+    if (MODE == WALK_STATS) {
+        a0 += x;
+        a1 = fmaf(x, x, a1);
+    } else {
+        const float xh = (x - mean) * invstd;
+        float dz = d;
+        if (RELU) dz = (__fadd_rn(__fmul_rn(g, xh), bt) > 0.0f) ? dz : 0.0f;
+        a0 = fmaf(dz, xh, a0);
+        a1 += dz;
+    }
+}
+
+template <int MODE, int VEC, bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_walk_small(
+    const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ tbl,
+    double *__restrict__ part, int N, int C, int P, BwdPlan pl) {
+    using U = typename Unit<VEC>::T;
+    __shared__ float sacc[2][kThreads * 4];
+    const int c0 = blockIdx.x * pl.CT;
+    const int ct = min(pl.CT, C - c0);
+    const int t = threadIdx.x;
+    const int r = t / pl.row_u;
+    const int u = t - r * pl.row_u;
+    const bool lane_on = (r < pl.npi) && (u * VEC < ct * P);
+    float mean[VEC], istd[VEC], g[VEC], bt[VEC], a0[VEC], a1[VEC];
+    int slot[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        a0[i] = 0.0f;
+        a1[i] = 0.0f;
+        const int er = u * VEC + i;
+        const int cc = lane_on ? er / P : 0;
+        slot[i] = (cc * pl.npi + r) * P + (er - cc * P);
+        mean[i] = istd[i] = g[i] = bt[i] = 0.0f;
+        if (MODE == WALK_BN_BWD) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + cc) * kTbl);
+            mean[i] = c4.x;
+            istd[i] = c4.y;
+            g[i] = c4.z;
+            bt[i] = c4.w;
+        }
+    }
+    if (lane_on) {
+        const int it0 = blockIdx.y * pl.ips, it1 = min(pl.iters, it0 + pl.ips);
+        size_t off = (static_cast<size_t>(it0 * pl.npi + r) * C + c0) * P + static_cast<size_t>(u) * VEC;
+        const size_t hop = static_cast<size_t>(C) * P * pl.npi;
+        int n = it0 * pl.npi + r;
+        U vdy{}, vx{};
+        if (n < N) {
+            vx = *reinterpret_cast<const U *>(xin + off);
+            if (MODE == WALK_BN_BWD) vdy = *reinterpret_cast<const U *>(dy + off);
+        }
+        for (int it = it0; it < it1 && n < N; ++it, n += pl.npi, off += hop) {
+            U ndy{}, nx{};
+            if (it + 1 < it1 && n + pl.npi < N) {
+                nx = *reinterpret_cast<const U *>(xin + off + hop);
+                if (MODE == WALK_BN_BWD) ndy = *reinterpret_cast<const U *>(dy + off + hop);
+            }
+            float d[VEC], x[VEC];
+            Unit<VEC>::get(vdy, d);
+            Unit<VEC>::get(vx, x);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) walk_accum<MODE, RELU>(d[i], x[i], mean[i], istd[i], g[i], bt[i], a0[i], a1[i]);
+            vdy = ndy;
+            vx = nx;
+        }
+    }
+    if (lane_on) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sacc[0][slot[i]] = a0[i];
+            sacc[1][slot[i]] = a1[i];
+        }
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    const int cnt = pl.npi * P;
+    for (int cc = wave; cc < ct; cc += kThreads / kWave) {
+        const float *p0 = sacc[0] + cc * cnt, *p1 = sacc[1] + cc * cnt;
+        double s0 = 0.0, s1 = 0.0;
+        for (int e = lane; e < cnt; e += kWave) {
+            s0 += static_cast<double>(p0[e]);
+            s1 += static_cast<double>(p1[e]);
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 0) * C + c0 + cc] = s0;
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 1) * C + c0 + cc] = s1;
+        }
+    }
+}
+
+template <int MODE, int VEC, bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_walk_large(
+    const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ tbl,
+    double *__restrict__ part, int N, int C, int P, BwdPlan pl) {
+    using U = typename Unit<VEC>::T;
+    __shared__ double red[8];
+    const int c = blockIdx.x;
+    float mean = 0.0f, istd = 0.0f, g = 0.0f, bt = 0.0f;
+    if (MODE == WALK_BN_BWD) {
+        const float4 c4 = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+        mean = c4.x;
+        istd = c4.y;
+        g = c4.z;
+        bt = c4.w;
+    }
+    double A0 = 0.0, A1 = 0.0;
+    const int n0 = blockIdx.y * pl.ips, n1 = min(N, n0 + pl.ips);
+    for (int n = n0; n < n1; ++n) {
+        const size_t base = (static_cast<size_t>(n) * C + c) * P;
+        float p0 = 0.0f, p1 = 0.0f;
+        for (int u = threadIdx.x; u < pl.row_u; u += kThreads) {
+            const size_t off = base + static_cast<size_t>(u) * VEC;
+            U vdy{};
+            const U vx = *reinterpret_cast<const U *>(xin + off);
+            if (MODE == WALK_BN_BWD) vdy = *reinterpret_cast<const U *>(dy + off);
+            float d[VEC], x[VEC];
+            Unit<VEC>::get(vdy, d);
+            Unit<VEC>::get(vx, x);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) walk_accum<MODE, RELU>(d[i], x[i], mean, istd, g, bt, p0, p1);
+        }
+        A0 += static_cast<double>(p0);
+        A1 += static_cast<double>(p1);
+    }
+    A0 = block_sum(A0, red);
+    A1 = block_sum(A1, red + 4);
+    if (threadIdx.x == 0) {
+        part[(static_cast<size_t>(blockIdx.y) * 2 + 0) * C + c] = A0;
+        part[(static_cast<size_t>(blockIdx.y) * 2 + 1) * C + c] = A1;
+    }
+}
+
+// ---- streaming passes ----
+template <bool RELU>
+__device__ __forceinline__ float bn_affine1(float x, const float4 &c) {       // c = {mean, invstd, gamma, beta}
+    const float y = __fadd_rn(__fmul_rn(c.z, (x - c.x) * c.y), c.w);
+    return RELU ? fmaxf(y, 0.0f) : y;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_fwd_v4(
+    const float4 *__restrict__ x, const float *__restrict__ tbl, float4 *__restrict__ y, unsigned n4,
+    FastDiv p4div, FastDiv cdiv, unsigned C, int with_sign, SignArgs sa, const float *__restrict__ gamma) {
+    __shared__ double red[12];
+    unsigned nblk = gridDim.x;
+    if (with_sign) {
+        nblk -= 1;
+        if (blockIdx.x == nblk) {
+            sign_loss_block(gamma, sa.b, sa.alpha, sa.margin, sa.l2, static_cast<int>(C), sa.loss, sa.acc,
+                            sa.bits, red);
+            return;
+        }
+    }
+    const unsigned step = nblk * kThreads;
+    unsigned q = blockIdx.x * kThreads + threadIdx.x;
+    for (; q + step < n4; q += 2 * step) {
+        const unsigned q1 = q + step;
+        const float4 v0 = x[q], v1 = x[q1];
+        const unsigned p0 = fdiv(q, p4div), p1 = fdiv(q1, p4div);
+        const unsigned c0 = p0 - fdiv(p0, cdiv) * C, c1 = p1 - fdiv(p1, cdiv) * C;
+        const float4 k0 = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0) * kTbl);
+        const float4 k1 = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c1) * kTbl);
+        y[q] = make_float4(bn_affine1<RELU>(v0.x, k0), bn_affine1<RELU>(v0.y, k0), bn_affine1<RELU>(v0.z, k0),
+                           bn_affine1<RELU>(v0.w, k0));
+        y[q1] = make_float4(bn_affine1<RELU>(v1.x, k1), bn_affine1<RELU>(v1.y, k1), bn_affine1<RELU>(v1.z, k1),
+                            bn_affine1<RELU>(v1.w, k1));
+    }
+    if (q < n4) {
+        const unsigned plane = fdiv(q, p4div);
+        const unsigned c = plane - fdiv(plane, cdiv) * C;
+        const float4 k = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+        const float4 v = x[q];
+        y[q] = make_float4(bn_affine1<RELU>(v.x, k), bn_affine1<RELU>(v.y, k), bn_affine1<RELU>(v.z, k),
+                           bn_affine1<RELU>(v.w, k));
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_fwd_s(
+    const float *__restrict__ x, const float *__restrict__ tbl, float *__restrict__ y, unsigned n, FastDiv pdiv,
+    FastDiv cdiv, unsigned C, int with_sign, SignArgs sa, const float *__restrict__ gamma) {
+    __shared__ double red[12];
+    unsigned nblk = gridDim.x;
+    if (with_sign) {
+        nblk -= 1;
+        if (blockIdx.x == nblk) {
+            sign_loss_block(gamma, sa.b, sa.alpha, sa.margin, sa.l2, static_cast<int>(C), sa.loss, sa.acc,
+                            sa.bits, red);
+            return;
+        }
+    }
+    const unsigned step = nblk * kThreads;
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += step) {
+        const unsigned plane = fdiv(i, pdiv);
+        const unsigned c = plane - fdiv(plane, cdiv) * C;
+        const float4 k = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+        y[i] = bn_affine1<RELU>(x[i], k);
+    }
+}
+
+// dx = gamma*invstd * (dz - c2 - xhat*c3), dz = dy masked by the recomputed ReLU; c = table rows.
+template <bool RELU>
+__device__ __forceinline__ float bn_bwd1(float d, float x, const float4 &a, const float4 &b) {
+    const float xh = (x - a.x) * a.y;
+    float dz = d;
+    if (RELU) dz = (__fadd_rn(__fmul_rn(a.z, xh), a.w) > 0.0f) ? dz : 0.0f;
+    return (a.z * a.y) * (dz - b.x - xh * b.y);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_bwd_v4(
+    const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
+    float4 *__restrict__ dx, unsigned n4, FastDiv p4div, FastDiv cdiv, unsigned C) {
+    const unsigned step = gridDim.x * kThreads;
+    unsigned q = blockIdx.x * kThreads + threadIdx.x;
+    for (; q + step < n4; q += 2 * step) {
+        const unsigned q1 = q + step;
+        const float4 d0 = dy[q], x0 = x[q], d1 = dy[q1], x1 = x[q1];
+        const unsigned p0 = fdiv(q, p4div), p1 = fdiv(q1, p4div);
+        const unsigned c0 = p0 - fdiv(p0, cdiv) * C, c1 = p1 - fdiv(p1, cdiv) * C;
+        const float4 *t0 = reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0) * kTbl);
+        const float4 *t1 = reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c1) * kTbl);
+        const float4 a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
+        dx[q] = make_float4(bn_bwd1<RELU>(d0.x, x0.x, a0, b0), bn_bwd1<RELU>(d0.y, x0.y, a0, b0),
+                            bn_bwd1<RELU>(d0.z, x0.z, a0, b0), bn_bwd1<RELU>(d0.w, x0.w, a0, b0));
+        dx[q1] = make_float4(bn_bwd1<RELU>(d1.x, x1.x, a1, b1), bn_bwd1<RELU>(d1.y, x1.y, a1, b1),
+                             bn_bwd1<RELU>(d1.z, x1.z, a1, b1), bn_bwd1<RELU>(d1.w, x1.w, a1, b1));
+    }
+    if (q < n4) {
+        const unsigned plane = fdiv(q, p4div);
+        const unsigned c = plane - fdiv(plane, cdiv) * C;
+        const float4 *t = reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+        const float4 a = t[0], b = t[1];
+        const float4 d = dy[q], v = x[q];
+        dx[q] = make_float4(bn_bwd1<RELU>(d.x, v.x, a, b), bn_bwd1<RELU>(d.y, v.y, a, b),
+                            bn_bwd1<RELU>(d.z, v.z, a, b), bn_bwd1<RELU>(d.w, v.w, a, b));
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_bwd_s(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ tbl,
+    float *__restrict__ dx, unsigned n, FastDiv pdiv, FastDiv cdiv, unsigned C) {
+    const unsigned step = gridDim.x * kThreads;
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += step) {
+        const unsigned plane = fdiv(i, pdiv);
+        const unsigned c = plane - fdiv(plane, cdiv) * C;
+        const float4 *t = reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+        dx[i] = bn_bwd1<RELU>(dy[i], x[i], t[0], t[1]);
+    }
+}
+
+// Finish of the fused backward: as k_passport_bwd_finish plus the table for the apply pass.
+// W-less form (dW == nullptr, s == nullptr) serves the public branch with learnable gamma/beta.
+struct BnBwdFinishArgs {
+    const float *tbl_in;       // forward table (mean, invstd, gamma, beta)
+    float *tbl_out;            // + c2, c3
+    double inv_m;              // 1/(N*HW); 0 in evaluation mode (statistics are constants: no mean terms)
+};
+
+template <bool VEC, int RPW>
+__global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
+    const double *__restrict__ part, int NS, int C, const float *__restrict__ b, float alpha, float margin,
+    float l2, const float *__restrict__ dloss, const float *__restrict__ dgamma_extra,
+    const float *__restrict__ dbeta_extra, const double *__restrict__ s, int K, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dW, BnBwdFinishArgs f) {
+    const int co0 = blockIdx.x * RPW;
+    const int lane = threadIdx.x & 63;
+    float dgv[RPW], dbv[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int co = min(co0 + r, C - 1);
+        double ag = 0.0, ab = 0.0;
+        for (int sp = lane; sp < NS; sp += kWave) {
+            ag += part[(static_cast<size_t>(sp) * 2 + 0) * C + co];
+            ab += part[(static_cast<size_t>(sp) * 2 + 1) * C + co];
+        }
+        ag = wave_sum(ag);
+        ab = wave_sum(ab);
+        const float4 t0 = *reinterpret_cast<const float4 *>(f.tbl_in + static_cast<size_t>(co) * kTbl);
+        float dg = static_cast<float>(ag), db = static_cast<float>(ab);
+        if (threadIdx.x == 0 && co0 + r < C) {
+            float4 *t = reinterpret_cast<float4 *>(f.tbl_out + static_cast<size_t>(co) * kTbl);
+            t[0] = t0;
+            t[1] = make_float4(static_cast<float>(ab * f.inv_m), static_cast<float>(ag * f.inv_m), 0.0f, 0.0f);
+        }
+        if (dgamma_extra) dg += dgamma_extra[co];
+        if (dbeta_extra) db += dbeta_extra[co];
+        if (dloss) dg += dloss[0] * sign_loss_grad1(t0.z, b[co], alpha, margin, l2);
+        dgv[r] = dg;
+        dbv[r] = db;
+        if (threadIdx.x == 0 && co0 + r < C) {
+            dgamma[co] = dg;
+            dbeta[co] = db;
+        }
+    }
+    if (dW) write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
@@ -750,24 +1184,22 @@ int launch_affine_fwd(const float *xhat, const float *gamma, const float *beta, 
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW / 4));
         const int grid = grid_for(n4) + (with_sign ? 1 : 0);
         if (relu)
-            hipLaunchKernelGGL(k_affine_fwd_v4<true>, dim3(grid), dim3(kThreads), 0, st,
-                               reinterpret_cast<const float4 *>(xhat), gamma, beta,
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_v4<true>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(xhat), gamma, beta,
                                reinterpret_cast<float4 *>(y), n4, pdiv, cdiv, static_cast<unsigned>(C),
                                with_sign ? 1 : 0, sa);
         else
-            hipLaunchKernelGGL(k_affine_fwd_v4<false>, dim3(grid), dim3(kThreads), 0, st,
-                               reinterpret_cast<const float4 *>(xhat), gamma, beta,
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(xhat), gamma, beta,
                                reinterpret_cast<float4 *>(y), n4, pdiv, cdiv, static_cast<unsigned>(C),
                                with_sign ? 1 : 0, sa);
     } else {
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
         const int grid = grid_for(total) + (with_sign ? 1 : 0);
         if (relu)
-            hipLaunchKernelGGL(k_affine_fwd_s<true>, dim3(grid), dim3(kThreads), 0, st, xhat, gamma, beta, y,
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_s<true>, dim3(grid), dim3(kThreads), st, xhat, gamma, beta, y,
                                static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C),
                                with_sign ? 1 : 0, sa);
         else
-            hipLaunchKernelGGL(k_affine_fwd_s<false>, dim3(grid), dim3(kThreads), 0, st, xhat, gamma, beta, y,
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_s<false>, dim3(grid), dim3(kThreads), st, xhat, gamma, beta, y,
                                static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C),
                                with_sign ? 1 : 0, sa);
     }
@@ -775,14 +1207,14 @@ int launch_affine_fwd(const float *xhat, const float *gamma, const float *beta, 
 }
 
 template <int VEC, bool RELU>
-void launch_bwd_t(const float *dy, const float *xh, const float *g, const float *bt, float *dx,
+void launch_bwd_t(ProfScope &prof, const float *dy, const float *xh, const float *g, const float *bt, float *dx,
                   double *part, int N, int C, int P, const BwdPlan &pl, hipStream_t st) {
     const dim3 grid(pl.tiles, pl.NS);
     if (pl.large)
-        hipLaunchKernelGGL((k_affine_bwd_large<VEC, RELU>), grid, dim3(kThreads), 0, st, dy, xh, g, bt, dx,
+        DEEPIPR_LAUNCH(prof, (k_affine_bwd_large<VEC, RELU>), grid, dim3(kThreads), st, dy, xh, g, bt, dx,
                            part, N, C, P, pl);
     else
-        hipLaunchKernelGGL((k_affine_bwd_small<VEC, RELU>), grid, dim3(kThreads), 0, st, dy, xh, g, bt, dx,
+        DEEPIPR_LAUNCH(prof, (k_affine_bwd_small<VEC, RELU>), grid, dim3(kThreads), st, dy, xh, g, bt, dx,
                            part, N, C, P, pl);
 }
 
@@ -793,11 +1225,11 @@ int launch_affine_bwd(const float *dy, const float *xh, const float *g, const fl
     if (pl.NS > 65535) return fail(DEEPIPR_EINVAL, "affine_relu_bwd: too many batch splits");
     ProfScope prof(DEEPIPR_K_AFFINE_BWD, st);
     if (pl.VEC == 4) {
-        if (relu) launch_bwd_t<4, true>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
-        else launch_bwd_t<4, false>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
+        if (relu) launch_bwd_t<4, true>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
+        else launch_bwd_t<4, false>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
     } else {
-        if (relu) launch_bwd_t<1, true>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
-        else launch_bwd_t<1, false>(dy, xh, g, bt, dx, part, N, C, P, pl, st);
+        if (relu) launch_bwd_t<1, true>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
+        else launch_bwd_t<1, false>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
     }
     *plan_out = pl;
     return check_launch("affine_relu_bwd");
@@ -860,8 +1292,9 @@ int deepipr_pooled_patch_mean(const float *keys, int nkeys, int B, int Ci, int H
     if (Ho <= 0 || Wo <= 0) return fail(DEEPIPR_EINVAL, "pooled_patch_mean: empty conv output");
     const int K = Ci * kh * kw;
     const dim3 grid((K + 3) / 4, nkeys);
-    ProfScope prof(DEEPIPR_K_POOLED_PATCH_MEAN, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(k_pooled_patch_mean, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream), keys,
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_POOLED_PATCH_MEAN, st0);
+    DEEPIPR_LAUNCH(prof, k_pooled_patch_mean, grid, dim3(kThreads), st0, keys,
                        B, Ci, H, W, kh, kw, stride, pad, Ho, Wo, m_out);
     return check_launch("pooled_patch_mean");
 }
@@ -874,11 +1307,11 @@ int deepipr_gamma_beta_fwd(const float *W, const double *s, int Co, int K, float
     const bool vec = K % 4 == 0 && aligned16(W) && aligned16(s);
     if (Co >= 2 * kRowPairMinCo) {               // enough rows to fill the chip with two per workgroup
         const dim3 grid((Co + 1) / 2);
-        if (vec) hipLaunchKernelGGL((k_gamma_beta<true, 2>), grid, dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
-        else hipLaunchKernelGGL((k_gamma_beta<false, 2>), grid, dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta<true, 2>), grid, dim3(kThreads), st, W, s, Co, K, gamma, beta);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta<false, 2>), grid, dim3(kThreads), st, W, s, Co, K, gamma, beta);
     } else {
-        if (vec) hipLaunchKernelGGL((k_gamma_beta<true, 1>), dim3(Co), dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
-        else hipLaunchKernelGGL((k_gamma_beta<false, 1>), dim3(Co), dim3(kThreads), 0, st, W, s, Co, K, gamma, beta);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta<true, 1>), dim3(Co), dim3(kThreads), st, W, s, Co, K, gamma, beta);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta<false, 1>), dim3(Co), dim3(kThreads), st, W, s, Co, K, gamma, beta);
     }
     return check_launch("gamma_beta_fwd");
 }
@@ -892,11 +1325,11 @@ int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double
     const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
     if (Co >= 2 * kRowPairMinCo) {
         const dim3 grid((Co + 1) / 2);
-        if (vec) hipLaunchKernelGGL((k_gamma_beta_bwd<true, 2>), grid, dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
-        else hipLaunchKernelGGL((k_gamma_beta_bwd<false, 2>), grid, dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 2>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 2>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
     } else {
-        if (vec) hipLaunchKernelGGL((k_gamma_beta_bwd<true, 1>), dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
-        else hipLaunchKernelGGL((k_gamma_beta_bwd<false, 1>), dim3(Co), dim3(kThreads), 0, st, dgamma, dbeta, s, Co, K, dW);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 1>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 1>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
     }
     return check_launch("gamma_beta_bwd");
 }
@@ -917,11 +1350,11 @@ int deepipr_gamma_beta_dkey(const float *dgamma, const float *dbeta, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *part = static_cast<double *>(workspace);
     ProfScope prof(DEEPIPR_K_DKEY, st);
-    hipLaunchKernelGGL(k_dkey_colsum, dim3((K + kThreads - 1) / kThreads, kDkeySplit), dim3(kThreads), 0, st,
+    DEEPIPR_LAUNCH(prof, k_dkey_colsum, dim3((K + kThreads - 1) / kThreads, kDkeySplit), dim3(kThreads), st,
                        dgamma, dbeta, W, Co, K, part);
     const int total = 2 * B * Ci * H * Wd;
     const double inv_n = 1.0 / (static_cast<double>(B) * Ho * Wo);
-    hipLaunchKernelGGL(k_dkey_gather, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part, K,
+    DEEPIPR_LAUNCH(prof, k_dkey_gather, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), st, part, K,
                        B, Ci, H, Wd, kh, kw, stride, pad, Ho, Wo, inv_n, dkeys);
     return check_launch("gamma_beta_dkey");
 }
@@ -950,7 +1383,7 @@ int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gam
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
     ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part,
+    DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), st, part,
                        pl.NS, C, dgamma, dbeta);
     return check_launch("affine_relu_bwd(finish)");
 }
@@ -958,8 +1391,9 @@ int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gam
 int deepipr_sign_loss_fwd(const float *gamma, const float *b, float alpha, float margin, float l2, int C,
                           float *loss, float *acc, int8_t *bits, void *stream) {
     if (!gamma || !b || !loss || !acc || C <= 0) return fail(DEEPIPR_EINVAL, "sign_loss_fwd: bad argument");
-    ProfScope prof(DEEPIPR_K_SIGN_LOSS_FWD, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(k_sign_loss_fwd, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), gamma, b,
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_SIGN_LOSS_FWD, st0);
+    DEEPIPR_LAUNCH(prof, k_sign_loss_fwd, dim3(1), dim3(kThreads), st0, gamma, b,
                        alpha, margin, l2, C, loss, acc, bits);
     return check_launch("sign_loss_fwd");
 }
@@ -967,9 +1401,10 @@ int deepipr_sign_loss_fwd(const float *gamma, const float *b, float alpha, float
 int deepipr_sign_loss_bwd(const float *dloss, const float *gamma, const float *b, float alpha, float margin,
                           float l2, int C, float *dgamma, void *stream) {
     if (!dloss || !gamma || !b || !dgamma || C <= 0) return fail(DEEPIPR_EINVAL, "sign_loss_bwd: bad argument");
-    ProfScope prof(DEEPIPR_K_SIGN_LOSS_BWD, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(k_sign_loss_bwd, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), dloss, gamma, b, alpha, margin, l2, C, dgamma);
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_SIGN_LOSS_BWD, st0);
+    DEEPIPR_LAUNCH(prof, k_sign_loss_bwd, dim3((C + kThreads - 1) / kThreads), dim3(kThreads),
+                   st0, dloss, gamma, b, alpha, margin, l2, C, dgamma);
     return check_launch("sign_loss_bwd");
 }
 
@@ -1009,14 +1444,201 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
 #define DEEPIPR_FINISH_ARGS part, pl.NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW
     if (C >= 2 * kRowPairMinCo) {
         const dim3 grid((C + 1) / 2);
-        if (vec) hipLaunchKernelGGL((k_passport_bwd_finish<true, 2>), grid, dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
-        else hipLaunchKernelGGL((k_passport_bwd_finish<false, 2>), grid, dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
     } else {
-        if (vec) hipLaunchKernelGGL((k_passport_bwd_finish<true, 1>), dim3(C), dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
-        else hipLaunchKernelGGL((k_passport_bwd_finish<false, 1>), dim3(C), dim3(kThreads), 0, st, DEEPIPR_FINISH_ARGS);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
     }
 #undef DEEPIPR_FINISH_ARGS
     return check_launch("passport_bwd(finish)");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm-fused passport layer
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int MODE, int VEC, bool RELU>
+void launch_walk_t(ProfScope &prof, const float *dy, const float *x, const float *tbl, double *part, int N, int C,
+                   int P, const BwdPlan &pl, hipStream_t st) {
+    const dim3 grid(pl.tiles, pl.NS);
+    if (pl.large)
+        DEEPIPR_LAUNCH(prof, (k_bn_walk_large<MODE, VEC, RELU>), grid, dim3(kThreads), st, dy, x, tbl, part, N, C, P, pl);
+    else
+        DEEPIPR_LAUNCH(prof, (k_bn_walk_small<MODE, VEC, RELU>), grid, dim3(kThreads), st, dy, x, tbl, part, N, C, P, pl);
+}
+
+template <int MODE>
+int launch_walk(const float *dy, const float *x, const float *tbl, double *part, int N, int C, int P, int relu,
+                BwdPlan *plan_out, hipStream_t st) {
+    const bool can_vec = aligned16(x) && (MODE == WALK_STATS || aligned16(dy));
+    const BwdPlan pl = plan_bwd(N, C, P, can_vec);
+    if (pl.NS > 65535) return fail(DEEPIPR_EINVAL, "bn walk: too many batch splits");
+    ProfScope prof(MODE == WALK_STATS ? DEEPIPR_K_BN_STATS : DEEPIPR_K_BN_BWD_REDUCE, st);
+    if (pl.VEC == 4) {
+        if (relu) launch_walk_t<MODE, 4, true>(prof, dy, x, tbl, part, N, C, P, pl, st);
+        else launch_walk_t<MODE, 4, false>(prof, dy, x, tbl, part, N, C, P, pl, st);
+    } else {
+        if (relu) launch_walk_t<MODE, 1, true>(prof, dy, x, tbl, part, N, C, P, pl, st);
+        else launch_walk_t<MODE, 1, false>(prof, dy, x, tbl, part, N, C, P, pl, st);
+    }
+    *plan_out = pl;
+    return check_launch("bn walk");
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW) {
+    if (bad_dims(N, C, HW)) return 0;
+    return bwd_workspace_bytes(N, C, HW);
+}
+
+int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
+                            const float *beta_in, const float *b, float alpha, float margin, float l2,
+                            float *running_mean, float *running_var, long long *num_batches_tracked,
+                            float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
+                            float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
+                            int8_t *bits, void *workspace, void *stream) {
+    if (!x || !y || !table || bad_dims(N, C, HW)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: bad argument");
+    if (W && (!m || !gamma || !beta || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: W needs m, gamma, beta, K");
+    if (!W && (!gamma_in || !beta_in)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: need W or gamma_in/beta_in");
+    if (training && !workspace) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: training needs a workspace");
+    if (!training && (!running_mean || !running_var))
+        return fail(DEEPIPR_EINVAL, "passport_bn_fwd: evaluation needs running statistics");
+    if ((running_mean == nullptr) != (running_var == nullptr))
+        return fail(DEEPIPR_EINVAL, "passport_bn_fwd: running_mean and running_var go together");
+    const bool with_sign = loss != nullptr;
+    if (with_sign && (!b || !acc)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: sign loss needs b and acc");
+    const size_t total = static_cast<size_t>(N) * C * HW;
+    if (total >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: tensor has >= 2^31 elements");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *part = static_cast<double *>(workspace);
+    BnFinishArgs f{};
+    const double M = static_cast<double>(N) * HW;
+    if (training) {
+        BwdPlan pl;
+        int rc = launch_walk<WALK_STATS>(nullptr, x, nullptr, part, N, C, HW, relu, &pl, st);
+        if (rc != DEEPIPR_OK) return rc;
+        f.part = part;
+        f.NS = pl.NS;
+    }
+    f.inv_m = 1.0 / M;
+    f.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.running_mean = running_mean;
+    f.running_var = running_var;
+    f.num_batches_tracked = num_batches_tracked;
+    f.tbl = table;
+    const float *g_for_sign = gamma_in;
+    {
+        ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
+        if (W) {
+            const bool vec = K % 4 == 0 && aligned16(W) && aligned16(m);
+            if (C >= 2 * kRowPairMinCo) {
+                const dim3 grid((C + 1) / 2);
+                if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bn<true, 2>), grid, dim3(kThreads), st, W, m, C, K, gamma, beta, f);
+                else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bn<false, 2>), grid, dim3(kThreads), st, W, m, C, K, gamma, beta, f);
+            } else {
+                if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bn<true, 1>), dim3(C), dim3(kThreads), st, W, m, C, K, gamma, beta, f);
+                else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bn<false, 1>), dim3(C), dim3(kThreads), st, W, m, C, K, gamma, beta, f);
+            }
+            g_for_sign = gamma;
+        } else {
+            DEEPIPR_LAUNCH(prof, k_bn_table, dim3((C + 3) / 4), dim3(kThreads), st, gamma_in, beta_in, C, f);
+        }
+        int rc = check_launch("passport_bn_fwd(finish)");
+        if (rc != DEEPIPR_OK) return rc;
+    }
+    SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
+    const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
+    ProfScope prof(DEEPIPR_K_BN_AFFINE_FWD, st);
+    if (HW % 4 == 0 && aligned16(x) && aligned16(y)) {
+        const unsigned n4 = static_cast<unsigned>(total / 4);
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW / 4));
+        const int grid = grid_for(n4) + (with_sign ? 1 : 0);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_v4<true>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(x), table, reinterpret_cast<float4 *>(y), n4, pdiv,
+                               cdiv, static_cast<unsigned>(C), with_sign ? 1 : 0, sa, g_for_sign);
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(x), table, reinterpret_cast<float4 *>(y), n4, pdiv,
+                               cdiv, static_cast<unsigned>(C), with_sign ? 1 : 0, sa, g_for_sign);
+    } else {
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
+        const int grid = grid_for(total) + (with_sign ? 1 : 0);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_s<true>, dim3(grid), dim3(kThreads), st, x, table, y,
+                               static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C),
+                               with_sign ? 1 : 0, sa, g_for_sign);
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_s<false>, dim3(grid), dim3(kThreads), st, x, table, y,
+                               static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C),
+                               with_sign ? 1 : 0, sa, g_for_sign);
+    }
+    return check_launch("passport_bn_fwd(apply)");
+}
+
+int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table, const double *m, const float *b,
+                            float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
+                            const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
+                            float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
+                            void *stream) {
+    if (!dy || !x || !table || !dx || !dgamma || !dbeta || !table_out || !workspace || bad_dims(N, C, HW))
+        return fail(DEEPIPR_EINVAL, "passport_bn_bwd: bad argument");
+    if (dW && (!m || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: dW needs m and K");
+    if (dloss && !b) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: sign loss needs b");
+    const size_t total = static_cast<size_t>(N) * C * HW;
+    if (total >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tensor has >= 2^31 elements");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *part = static_cast<double *>(workspace);
+    BwdPlan pl;
+    int rc = launch_walk<WALK_BN_BWD>(dy, x, table, part, N, C, HW, relu, &pl, st);
+    if (rc != DEEPIPR_OK) return rc;
+    BnBwdFinishArgs f{table, table_out, training ? 1.0 / (static_cast<double>(N) * HW) : 0.0};
+    {
+        ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
+        const bool vec = dW && K % 4 == 0 && aligned16(dW) && aligned16(m);
+#define DEEPIPR_BNFIN_ARGS part, pl.NS, C, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, m, K, dgamma, dbeta, dW, f
+        if (C >= 2 * kRowPairMinCo) {
+            const dim3 grid((C + 1) / 2);
+            if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bn_bwd_finish<true, 2>), grid, dim3(kThreads), st, DEEPIPR_BNFIN_ARGS);
+            else DEEPIPR_LAUNCH(prof, (k_passport_bn_bwd_finish<false, 2>), grid, dim3(kThreads), st, DEEPIPR_BNFIN_ARGS);
+        } else {
+            if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bn_bwd_finish<true, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_BNFIN_ARGS);
+            else DEEPIPR_LAUNCH(prof, (k_passport_bn_bwd_finish<false, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_BNFIN_ARGS);
+        }
+#undef DEEPIPR_BNFIN_ARGS
+        rc = check_launch("passport_bn_bwd(finish)");
+        if (rc != DEEPIPR_OK) return rc;
+    }
+    const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
+    ProfScope prof(DEEPIPR_K_BN_AFFINE_BWD, st);
+    if (HW % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx)) {
+        const unsigned n4 = static_cast<unsigned>(total / 4);
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW / 4));
+        const int grid = grid_for(n4);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_v4<true>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x), table_out,
+                               reinterpret_cast<float4 *>(dx), n4, pdiv, cdiv, static_cast<unsigned>(C));
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x), table_out,
+                               reinterpret_cast<float4 *>(dx), n4, pdiv, cdiv, static_cast<unsigned>(C));
+    } else {
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
+        const int grid = grid_for(total);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_s<true>, dim3(grid), dim3(kThreads), st, dy, x, table_out, dx,
+                               static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C));
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_s<false>, dim3(grid), dim3(kThreads), st, dy, x, table_out, dx,
+                               static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C));
+    }
+    return check_launch("passport_bn_bwd(apply)");
 }
 
 }  // extern "C"

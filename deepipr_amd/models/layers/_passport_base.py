@@ -67,6 +67,7 @@ class PassportLayerBase(nn.Module):
         self.bn = norm if norm is not None else nn.Sequential()
         self.relu = nn.ReLU(inplace=True) if relu else None
         self._pooled = P.PooledKeys()
+        self.fuse_norm = True          # fold BatchNorm(affine=False) into the passport kernels when possible
         self.reset_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -192,13 +193,26 @@ class PassportLayerBase(nn.Module):
             self.set_key(torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device),
                          torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device))
         x = self.conv(x)
-        x = self.bn(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
         p_bias = self._use_param(self.bias, force_passport, ind)
+        sl = self._sign()
+        if self.fuse_norm and P.bn_is_fusable(self.bn) and p_scale == p_bias:
+            # BatchNorm(affine=False) folded into the passport kernels: 3 launches forward, 3 backward,
+            # the normalised activation is never written (deepipr_passport_bn_fwd / _bwd)
+            if p_scale:
+                return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu)
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
+                x, self.weight, skey, key, self.b if sl is not None else None, m, self.bn, self.alpha, relu,
+                stride, pad)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
+        x = self.bn(x)
         if p_scale and p_bias:                       # public branch: learnable affine, no sign loss
             return P.affine_relu(x, self.scale, self.bias, relu)
-        sl = self._sign()
         if not p_scale and not p_bias:               # passport branch: the fused two-launch layer
             skey, key, m, stride, pad = self._pooled_means()
             y, gamma, _beta, loss, acc, _bits = P.passport_layer(

@@ -192,6 +192,56 @@ class HipKernels:
         return dx, dw, dgb[0], dgb[1]
 
 
+    def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
+                        momentum, eps, training, margin=MARGIN, l2=L2):
+        """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x.
+        -> y, table[C,8], gamma, beta, loss, acc, bits  (gamma/beta None on the W-less public branch)."""
+        dev = _chk(x, weight, m, gamma_in, beta_in, b, running_mean, running_var)
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        lib = _lib.lib()
+        y = torch.empty_like(x)
+        table = torch.empty((c, 8), dtype=torch.float32, device=dev)
+        gb = sl = bits = ws = None
+        k = 0
+        if weight is not None:
+            gb = torch.empty((2, c), dtype=torch.float32, device=dev)
+            k = weight.numel() // c
+        if b is not None:
+            sl = torch.empty(2, dtype=torch.float32, device=dev)
+            bits = torch.empty(c, dtype=torch.int8, device=dev)
+        if training:
+            ws = torch.empty(lib.deepipr_passport_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _lib.check(lib.deepipr_passport_bn_fwd(
+                _p(x), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2, _p(running_mean),
+                _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu), _p(y), _p(table),
+                _p(gb[0]) if gb is not None else None, _p(gb[1]) if gb is not None else None,
+                _p(sl[0]) if sl is not None else None, _p(sl[1]) if sl is not None else None, _p(bits), _p(ws),
+                _stream(dev)), 'passport_bn_fwd')
+        return (y, table, gb[0] if gb is not None else None, gb[1] if gb is not None else None,
+                sl[0] if sl is not None else None, sl[1] if sl is not None else None, bits)
+
+    def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
+                        margin=MARGIN, l2=L2):
+        """-> dx, dW (None when wshape is None), dgamma, dbeta."""
+        dev = _chk(dy, x, table, m, b, dloss, dgamma_extra, dbeta_extra)
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        lib = _lib.lib()
+        ws = torch.empty(lib.deepipr_passport_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        table_out = torch.empty_like(table)
+        with _on(dev):
+            _lib.check(lib.deepipr_passport_bn_bwd(
+                _p(dy), _p(x), _p(table), _p(m), _p(b), alpha, margin, l2, _p(dloss), _p(dgamma_extra),
+                _p(dbeta_extra), int(training), n, c, hw, (dw.numel() // c) if dw is not None else 0, int(relu),
+                _p(dx), _p(dw), _p(dgb[0]), _p(dgb[1]), _p(table_out), _p(ws), _stream(dev)), 'passport_bn_bwd')
+        return dx, dw, dgb[0], dgb[1]
+
+
 kernels = HipKernels()
 
 
@@ -329,6 +379,75 @@ class _PassportLayer(torch.autograd.Function):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, weight, key_shape, stride, pad)
         return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None)
+
+
+class _PassportBNLayer(torch.autograd.Function):
+    """BatchNorm2d(affine=False) + passport affine + ReLU + sign loss, fused: three launches forward, three
+    backward, the normalised activation is never written.  With weight=None it is the public branch of a
+    PassportPrivateBlock (learnable gamma_in / beta_in)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, cfg):
+        alpha, relu, stride, pad, training, momentum, eps = cfg
+        x = x.contiguous()
+        w = None if weight is None else weight.contiguous()
+        gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
+        bi = None if beta_in is None else beta_in.contiguous().view(-1)
+        bb = None if b is None else b.contiguous().view(-1)
+        y, table, gamma, beta, loss, acc, bits = kernels.passport_bn_fwd(
+            x, w, m, gi, bi, bb, float(alpha), relu, running_mean, running_var, nbt, float(momentum), float(eps),
+            training)
+        ctx.save_for_backward(x, w, table, m, bb)
+        ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
+        # running_mean / running_var / num_batches_tracked are plain buffers updated in place by the kernel
+        if gamma is None:
+            gamma = beta = x.new_zeros(0)
+        if loss is None:
+            loss = acc = x.new_zeros(())
+            bits = torch.zeros(0, dtype=torch.int8, device=x.device)
+        ctx.mark_non_differentiable(acc, bits)
+        return y, gamma, beta, loss, acc, bits
+
+    @staticmethod
+    def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
+        x, w, table, m, bb = ctx.saved_tensors
+        alpha, relu, stride, pad, training, key_shape = ctx.cfg
+        if dy is None:
+            dy = torch.zeros_like(x)
+        dl = None if (bb is None or dloss is None) else dloss.contiguous()
+        if w is None:
+            dgamma_extra = dbeta_extra = None
+        dx, dw, dg, db = kernels.passport_bn_bwd(dy.contiguous(), x, table, m, bb, alpha, dl,
+                                                 _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
+                                                 None if w is None else w.shape, relu, training)
+        dsk = dk = None
+        if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
+        return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
+                dg if w is None else None, db if w is None else None, None, None, None, None, None, None)
+
+
+def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad):
+    """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False)."""
+    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps)
+    return _PassportBNLayer.apply(x, weight, skey, key, None, None, b, m, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked if bn.training else None, cfg)
+
+
+def bn_affine_relu(x, gamma, beta, bn, relu=True):
+    """Fused public branch: BatchNorm2d(affine=False) + learnable gamma/beta + ReLU."""
+    cfg = (0.0, bool(relu), 1, 0, _bn_uses_batch_stats(bn), bn.momentum, bn.eps)
+    return _PassportBNLayer.apply(x, None, None, None, gamma, beta, None, None, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked if bn.training else None, cfg)[0]
+
+
+def _bn_uses_batch_stats(bn):
+    return bn.training or bn.running_mean is None
+
+
+def bn_is_fusable(bn):
+    """nn.BatchNorm2d without affine parameters and with the default exponential running average."""
+    return (isinstance(bn, torch.nn.BatchNorm2d) and not bn.affine and bn.momentum is not None)
 
 
 def affine_relu(xhat, gamma, beta, relu=True):

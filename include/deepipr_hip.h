@@ -35,9 +35,11 @@ int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
 
 /* Opt-in in-situ timing (the one piece of process-global state, off by default): while enabled every
- * kernel launch below is bracketed by two hipEvents recorded on the launch stream.  read() waits for
- * the recorded events and returns the accumulated milliseconds / launch count of one kernel since the
- * last enable(1).  Must be off during hipGraph capture. */
+ * kernel below is dispatched through hipExtLaunchKernelGGL with a start and a stop hipEvent attached to
+ * its own dispatch packet on the launch stream, so the elapsed time is the kernel's execution time (what
+ * rocprofv3's kernel trace reports), free of event-record overhead.  read() waits for the events and
+ * returns the accumulated milliseconds / launch count of one kernel since the last enable(1).  Must be
+ * off during hipGraph capture. */
 #define DEEPIPR_K_POOLED_PATCH_MEAN 0
 #define DEEPIPR_K_GAMMA_BETA_FWD 1
 #define DEEPIPR_K_GAMMA_BETA_BWD 2
@@ -48,8 +50,12 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_SIGN_LOSS_FWD 7
 #define DEEPIPR_K_SIGN_LOSS_BWD 8
 #define DEEPIPR_K_DKEY 9
-#define DEEPIPR_K_NULL_BRACKET 10   /* empty event pair recorded after every 4th launch: bracket overhead */
-#define DEEPIPR_PROFILE_KERNELS 11
+#define DEEPIPR_K_RESERVED 10
+#define DEEPIPR_K_BN_STATS 11
+#define DEEPIPR_K_BN_AFFINE_FWD 12
+#define DEEPIPR_K_BN_BWD_REDUCE 13
+#define DEEPIPR_K_BN_AFFINE_BWD 14
+#define DEEPIPR_PROFILE_KERNELS 15
 int deepipr_profile_enable(int on);
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 
@@ -141,6 +147,35 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
                          int N, int C, int HW, int K, int relu,
                          float *dxhat, float *dW, float *dgamma, float *dbeta,
                          void *workspace, void *stream);
+
+/* ------------------------------------------------------------------ BatchNorm-fused passport layer
+ * The passport layer's norm is BatchNorm2d(o, affine=False) by default (passportconv2d.py:57-58).  These two
+ * entry points take the CONV OUTPUT x and do norm + passport affine + ReLU (+ sign loss) without ever
+ * materialising the normalised activation:
+ *   forward  (3 launches): per-channel sums of x, x^2  ->  gamma/beta GEMV + statistics finish (mean, invstd,
+ *            running-stat update with `momentum`, unbiased variance)  ->  y = relu(gamma*((x-mean)*invstd)+beta)
+ *   backward (3 launches): sums of dz*xhat and dz  ->  dgamma/dbeta/dW finish  ->
+ *            dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+ * replaces: self.bn(x) (native_batch_norm + native_batch_norm_backward, passportconv2d.py:219) and everything
+ *           deepipr_passport_fwd / _bwd replace.
+ * table, table_out: [C][8] floats {mean, invstd, gamma, beta, c2, c3, -, -}; `table` from forward is the only
+ * per-channel state backward needs.  W == NULL selects the public branch of PassportPrivateBlock: gamma_in /
+ * beta_in are the learnable scale / bias (passportconv2d_private.py:140-141,162-163), dW is not produced.
+ * training == 0 uses the running statistics (eval mode) and backward treats them as constants.
+ * running_mean / running_var / num_batches_tracked may be NULL (track_running_stats=False) when training.
+ * workspace: deepipr_passport_bn_workspace_bytes(N, C, HW) bytes (forward needs it only when training). */
+size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
+int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
+                            const float *beta_in, const float *b, float alpha, float margin, float l2,
+                            float *running_mean, float *running_var, long long *num_batches_tracked,
+                            float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
+                            float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
+                            int8_t *bits, void *workspace, void *stream);
+int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table, const double *m, const float *b,
+                            float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
+                            const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
+                            float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
+                            void *stream);
 
 #ifdef __cplusplus
 }

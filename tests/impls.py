@@ -45,8 +45,9 @@ class ProductImpl:
     """The HIP build (deepipr_amd).  On the GPU box it runs the real kernels on cuda:0; the CPU suite
     passes device='cpu' after monkeypatching passport_ops.kernels with tests/oracle_kernels.py."""
 
-    def __init__(self, device='cuda:0'):
+    def __init__(self, device='cuda:0', fuse_norm=True):
         self.device = torch.device(device)
+        self.fuse_norm = fuse_norm
 
     def build(self, case):
         from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
@@ -61,6 +62,9 @@ class ProductImpl:
             model = (AlexNetPassportPrivate if private else AlexNetPassport)(3, case['ncls'], kw)
         else:
             model = (ResNet18Private if private else ResNet18Passport)(num_classes=case['ncls'], passport_kwargs=kw)
+        for m in model.modules():
+            if self.is_passport(m):
+                m.fuse_norm = self.fuse_norm     # BatchNorm folded into the passport kernels, or the unfused ops
         return model.to(self.device)
 
     def is_passport(self, m):

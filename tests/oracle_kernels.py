@@ -85,3 +85,55 @@ class OracleKernels:
         if dloss is not None:
             dg = dg + self.sign_loss_bwd(dloss, gamma, b, alpha, margin, l2)
         return dx, self.gamma_beta_bwd(dg, db, m, wshape), dg, db
+
+    # ---- BatchNorm-fused entry points: stock ATen batch_norm on the host as the checker ----
+    def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
+                        momentum, eps, training, margin=npp.MARGIN, l2=npp.L2):
+        import torch.nn.functional as F
+        x64 = x.detach().double()
+        if training:
+            mean = x64.mean(dim=(0, 2, 3))
+            var = x64.var(dim=(0, 2, 3), unbiased=False)
+            if running_mean is not None:
+                mm = x.numel() // x.shape[1]
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+                    running_var.mul_(1 - momentum).add_(momentum * (var * mm / max(1, mm - 1)).float())
+                    if nbt is not None:
+                        nbt.add_(1)
+        else:
+            mean, var = running_mean.double(), running_var.double()
+        invstd = 1.0 / torch.sqrt(var + eps)
+        if weight is not None:
+            gamma, beta = self.gamma_beta_fwd(weight, m)
+        else:
+            gamma, beta = gamma_in.detach().reshape(-1), beta_in.detach().reshape(-1)
+        xh = ((x64 - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)).float()
+        y = self.affine_relu_fwd(xh, gamma, beta, relu)
+        table = torch.zeros(x.shape[1], 8)
+        table[:, 0], table[:, 1], table[:, 2], table[:, 3] = mean.float(), invstd.float(), gamma, beta
+        if b is None:
+            return y, table, (gamma if weight is not None else None), (beta if weight is not None else None), None, None, None
+        loss, acc, bits = self.sign_loss_fwd(gamma, b, alpha, margin, l2)
+        return y, table, gamma, beta, loss, acc, bits
+
+    def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
+                        margin=npp.MARGIN, l2=npp.L2):
+        mean, invstd, gamma, beta = [table[:, i].double() for i in range(4)]
+        x64, dy64 = x.detach().double(), dy.detach().double()
+        xh = (x64 - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        z32 = npp.affine_relu_fwd(xh.float().numpy(), table[:, 2].numpy(), table[:, 3].numpy(), False)
+        dz = torch.where(torch.from_numpy(z32 > 0), dy64, torch.zeros_like(dy64)) if relu else dy64
+        s_dzx, s_dz = (dz * xh).sum(dim=(0, 2, 3)), dz.sum(dim=(0, 2, 3))
+        mm = x.numel() // x.shape[1]
+        c2, c3 = (s_dz / mm, s_dzx / mm) if training else (torch.zeros_like(s_dz), torch.zeros_like(s_dz))
+        dx = (gamma * invstd).view(1, -1, 1, 1) * (dz - c2.view(1, -1, 1, 1) - xh * c3.view(1, -1, 1, 1))
+        dg, db = s_dzx.float(), s_dz.float()
+        if dgamma_extra is not None:
+            dg = dg + dgamma_extra
+        if dbeta_extra is not None:
+            db = db + dbeta_extra
+        if dloss is not None:
+            dg = dg + self.sign_loss_bwd(dloss, table[:, 2].contiguous(), b, alpha, margin, l2)
+        dw = self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None
+        return dx.float(), dw, dg, db

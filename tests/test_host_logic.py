@@ -35,11 +35,14 @@ def test_product_refuses_cpu_tensors():
         blk(torch.randn(2, 4, 8, 8))
 
 
+@pytest.mark.parametrize('fuse_norm', [True, False])
 @pytest.mark.parametrize('name', list(CASES))
-def test_host_wiring_matches_reference(name, golden_dir, cpu_kernels):
+def test_host_wiring_matches_reference(name, fuse_norm, golden_dir, cpu_kernels):
+    if not fuse_norm and CASES[name]['norm'] != 'bn':
+        pytest.skip('only BatchNorm layers have a fused variant')
     torch.set_num_threads(8)
     gold = load_golden(golden_dir, name)
-    got = runner.collect(name, ProductImpl('cpu'))
+    got = runner.collect(name, ProductImpl('cpu', fuse_norm=fuse_norm))
     compare_case(got, gold, rtol=2e-5, atol=2e-6, skip_prefixes=('train/acc',))
     # same torch seed -> same constructor RNG draws as the reference: signature vectors identical
     for k in gold:
