@@ -113,6 +113,50 @@ def cpu_baseline(args, budget_s=20.0):
                       % (n, args.batch, dt, threads, torch.__version__)}
 
 
+def stress_roofline(device, reps=30):
+    """The same dominant kernel pair on a tensor large enough to leave the caches (S3 [512,512,8,8], 67 MB
+    per tensor, 201 MB of algorithmic traffic per backward-apply launch), timed with the library's own
+    per-dispatch events.  Kernel quality evidence next to the launch-bound in-situ figure."""
+    from deepipr_amd.passport_ops import kernels as K
+    n, c, h, w = 512, 512, 8, 8
+    x = torch.randn(n, c, h, w, device=device)
+    dy = torch.randn(n, c, h, w, device=device)
+    g, b = torch.randn(c, device=device), torch.randn(c, device=device)
+    rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+
+    def once():
+        out = K.passport_bn_fwd(x, None, None, g, b, None, 0.0, True, rm, rv, None, 0.1, 1e-5, True)
+        K.passport_bn_bwd(dy, x, out[1], None, None, 0.0, None, None, None, None, True, True)
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    el = x.numel()
+    res = {}
+    for name, bpe in (('bn_affine_bwd', 12), ('bn_affine_fwd', 8), ('bn_bwd_reduce', 8), ('bn_stats', 4)):
+        ms, cnt = prof[name]
+        us = 1000.0 * ms / cnt
+        res[name] = {'avg_us': round(us, 2), 'GBps': round(bpe * el / (us * 1e-6) / 1e9, 1)}
+    a = res['bn_affine_bwd']
+    return {'bound': 'hbm', 'kernel': 'k_bn_affine_bwd', 'shape': [n, c, h, w], 'achieved': a['GBps'],
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
+            'bytes_per_launch': 12 * el, 'avg_us': a['avg_us'], 'kernels': res}
+
+
+def pmc_traffic(kernel, shape_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic.json), or None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))[kernel][shape_key]
+        return int(rec['fetch'] + rec['write'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -123,6 +167,7 @@ def main():
     ap.add_argument('--classes', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
     args = ap.parse_args()
 
     rank, local_rank, world = D.init_from_env()
@@ -204,12 +249,16 @@ def main():
         out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (passport %s backward pass: read dy + x, write dx)' % (
                                dom, 'norm+affine' if dom.startswith('bn') else 'affine'),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': round(a['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                           'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
+                           'traffic': pmc_traffic('k_' + dom, 'R[%d,512,4,4]' % args.batch),
                            'bytes_per_launch': int(12 * per_launch_elems), 'avg_us': a['avg_us'],
                            'note': '12 B/elt x %d elts per launch; tensors are %.1f MB (L2/MALL-resident, '
                                    'launch-latency bound at this shape)' % (per_launch_elems,
                                                                            4 * per_launch_elems / 1e6)}
         out['kernels'] = kern
+        if args.gpus == 1 and not args.no_stress:
+            out['roofline_stress'] = stress_roofline(device)
+            out['roofline_stress']['traffic'] = pmc_traffic('k_' + dom, 'S3[512,512,8,8]')
     if args.gpus == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out))

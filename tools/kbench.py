@@ -55,6 +55,13 @@ def main():
         res.append(('affine_fwd', name, t, 8 * el / t / 1e3))
         t = timed(lambda: K.affine_relu_bwd(dy, x, g, b, True))
         res.append(('affine_bwd(+finish)', name, t, 12 * el / t / 1e3))
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+
+        def fused():
+            out = K.passport_bn_fwd(x, None, None, g, b, None, 0.0, True, rm, rv, None, 0.1, 1e-5, True)
+            K.passport_bn_bwd(dy, x, out[1], None, None, 0.0, None, None, None, None, True, True)
+        t = timed(fused)
+        res.append(('bn fused fwd+bwd (32B)', name, t, 32 * el / t / 1e3))
         cpy = torch.empty_like(x)
         t = timed(lambda: cpy.copy_(x))
         res.append(('torch copy_ (8B/elt)', name, t, 8 * el / t / 1e3))
