@@ -168,6 +168,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph (1 GPU only)')
     args = ap.parse_args()
 
     rank, local_rank, world = D.init_from_env()
@@ -195,6 +196,13 @@ def main():
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
 
+    if args.graph:
+        assert world == 1, '--graph is single-GPU only'
+        from deepipr_amd.experiments.graph_step import GraphedTrainStep
+        fn = train_step_v1 if args.scheme == 1 else train_step_v23
+        graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0])
+        step = lambda i: graphed(xs[i % nb], ys[i % nb])
+        args.no_kernel_timing = True                       # per-dispatch events cannot be captured
     for i in range(args.warmup):
         step(i)
     timing = not args.no_kernel_timing
@@ -226,7 +234,7 @@ def main():
                                'CIFAR%d 3x32x32, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                ('1' if args.scheme == 1 else '2 private', args.classes, args.batch),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
-                   'passport_layers': len(elems)},
+                   'passport_layers': len(elems), 'launch': 'hipGraph replay' if args.graph else 'eager'},
     }
     dom = 'bn_affine_bwd' if prof.get('bn_affine_bwd', (0, 0))[1] > 0 else 'affine_bwd'
     if timing and prof.get(dom, (0, 0))[1] > 0:

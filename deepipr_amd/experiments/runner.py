@@ -148,10 +148,10 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
     if private:
         net = D.replicate(DualBranch(model), device)
-        trainer = TrainerPrivate(net, opt, sched, device)
+        trainer = TrainerPrivate(net, opt, sched, device, graph=bool(args.get('graph')) and world == 1)
     else:
         net = D.replicate(model, device)
-        trainer = Trainer(net, opt, sched, device)
+        trainer = Trainer(net, opt, sched, device, graph=bool(args.get('graph')) and world == 1)
 
     scheme = scheme_of(args, private)
     logdir = os.path.join(args.get('logdir') or 'logs', '%s_%s_v%d%s' % (

@@ -101,13 +101,37 @@ class Tester(object):
         return {'loss': loss, 'acc': acc, 'time': time.time() - start}
 
 
+class StepRunner:
+    """Runs step_fn eagerly, or -- graph=True, single GPU, fixed batch shape -- from a hipGraph captured on the
+    first full batch (experiments/graph_step.py); ragged last batches fall back to the eager step."""
+
+    def __init__(self, step_fn, model, optimizer, graph=False):
+        self.step_fn, self.model, self.optimizer = step_fn, model, optimizer
+        self.graph = graph
+        self._graphed = None
+        self._shape = None
+
+    def __call__(self, data, target):
+        if not self.graph or not data.is_cuda:
+            return self.step_fn(self.model, self.optimizer, data, target)
+        if self._graphed is None:
+            from deepipr_amd.experiments.graph_step import GraphedTrainStep
+            self._graphed = GraphedTrainStep(self.step_fn, self.model, self.optimizer, data, target, warmup=0)
+            self._shape = (tuple(data.shape), tuple(target.shape))
+            return self._graphed(data, target)          # capture does not execute: replay the first batch
+        if (tuple(data.shape), tuple(target.shape)) != self._shape:
+            return self.step_fn(self.model, self.optimizer, data, target)
+        return self._graphed(data, target)
+
+
 class Trainer(object):
-    def __init__(self, model, optimizer, scheduler, device, log_interval=0):
+    def __init__(self, model, optimizer, scheduler, device, log_interval=0, graph=False):
         self.model = model
         self.optimizer = optimizer
         self.scheduler = scheduler
         self.device = device
         self.log_interval = log_interval
+        self.step = StepRunner(train_step_v1, model, optimizer, graph)
 
     def train(self, e, dataloader, wm_dataloader=None):
         self.model.train()
@@ -122,7 +146,7 @@ class Trainer(object):
                 wm_data, wm_target = next_trigger_batch(wm_state, wm_dataloader)
                 data = torch.cat([data, wm_data.to(dev, non_blocking=True)], dim=0)
                 target = torch.cat([target, wm_target.to(dev, non_blocking=True)], dim=0)
-            loss, sign_loss, acc = train_step_v1(self.model, self.optimizer, data, target)
+            loss, sign_loss, acc = self.step(data, target)
             meters += torch.stack([sign_loss, loss, acc])
             if self.log_interval and (i + 1) % self.log_interval == 0:
                 s, l, a = (meters / (i + 1)).tolist()

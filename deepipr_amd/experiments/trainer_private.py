@@ -11,8 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from deepipr_amd.experiments.trainer import (accuracy, mean_sign_acc, next_trigger_batch, reset_sign_losses,
-                                             total_sign_loss)
+from deepipr_amd.experiments.trainer import (StepRunner, accuracy, mean_sign_acc, next_trigger_batch,
+                                             reset_sign_losses, total_sign_loss)
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
 
@@ -104,9 +104,10 @@ class TesterPrivate(object):
 
 
 class TrainerPrivate(object):
-    def __init__(self, model, optimizer, scheduler, device, log_interval=0):
+    def __init__(self, model, optimizer, scheduler, device, log_interval=0, graph=False):
         self.model = model
         self.dual = model if isinstance(_strip_ddp(model), DualBranch) else DualBranch(model)
+        self.step = StepRunner(train_step_v23, self.dual, optimizer, graph)
         self.optimizer = optimizer
         self.scheduler = scheduler
         self.device = device
@@ -126,7 +127,7 @@ class TrainerPrivate(object):
                 wm_data, wm_target = next_trigger_batch(wm_state, wm_dataloader)
                 data = torch.cat([data, wm_data.to(dev, non_blocking=True)], dim=0)
                 target = torch.cat([target, wm_target.to(dev, non_blocking=True)], dim=0)
-            meters += torch.stack(train_step_v23(self.dual, self.optimizer, data, target))
+            meters += torch.stack(self.step(data, target))
             if self.log_interval and (i + 1) % self.log_interval == 0:
                 l, s, pu, pr = (meters / (i + 1)).tolist()
                 print(f'Epoch {e:3d} [{i:4d}/{len(dataloader):4d}] Loss: {l:6.4f} Sign Loss: {s:6.4f} '

@@ -178,12 +178,18 @@ class PassportLayerBase(nn.Module):
         """Pre-size the lazily created tensors so strict loads of reference checkpoints succeed
         (passportconv2d.py:177-196)."""
         dev = self.weight.device
+        # (unlike the reference, tensors that already have the right shape are kept, so an optimiser or a
+        # captured hipGraph holding them stays valid across a load)
         for name in (self.KEY, self.SKEY):
             if prefix + name in state_dict:
-                self.register_buffer(name, torch.empty(state_dict[prefix + name].size(), device=dev))
+                cur, want = getattr(self, name), state_dict[prefix + name].size()
+                if cur is None or cur.size() != want:
+                    self.register_buffer(name, torch.empty(want, device=dev))
         for name in ('scale', 'bias'):
             if prefix + name in state_dict:
-                setattr(self, name, nn.Parameter(torch.empty(state_dict[prefix + name].size(), device=dev)))
+                cur, want = getattr(self, name), state_dict[prefix + name].size()
+                if cur is None or cur.size() != want:
+                    setattr(self, name, nn.Parameter(torch.empty(want, device=dev)))
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
 

@@ -493,6 +493,91 @@ def test_signature_embeds_and_reads_back_bit_exact():
     assert float(blk.sign_loss.acc) == 1.0
 
 
+def test_graphed_step_equals_eager_step():
+    """hipGraph-captured V2 step (dual forward, fused-BN passport kernels inside the graph) replays to the same
+    weights as the eager step."""
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    results = []
+    for graphed in (False, True):
+        prod, _ref, x, y = _fullsize_pair(True, 32, 100)
+        x, y = x.to(DEV), y.to(DEV)
+        dual = DualBranch(prod)
+        opt = torch.optim.SGD(prod.parameters(), **SGD)
+        bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+        try:
+            if graphed:
+                snap = {k: v.clone() for k, v in prod.state_dict().items()}
+                g = GraphedTrainStep(train_step_v23, dual, opt, x, y, warmup=2)
+                prod.load_state_dict(snap)                    # undo the warm-up / capture steps
+                for st in opt.state.values():
+                    st['momentum_buffer'].zero_()
+                for _ in range(3):
+                    out = g(x, y)
+            else:
+                for _ in range(3):
+                    out = train_step_v23(dual, opt, x, y)
+            torch.cuda.synchronize()
+        finally:
+            torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+        results.append(({k: v.clone() for k, v in prod.state_dict().items()}, [float(o) for o in out]))
+    (sd_e, out_e), (sd_g, out_g) = results
+    for a, b in zip(out_e, out_g):
+        assert a == pytest.approx(b, rel=1e-4, abs=1e-5)
+    for k in sd_e:
+        if sd_e[k].dtype.is_floating_point:
+            assert torch.allclose(sd_e[k], sd_g[k], rtol=1e-3, atol=1e-5), k
+
+
+def test_trainer_graph_mode_equals_eager_epoch():
+    """Trainer(graph=True): captured on the first batch (without advancing training), replayed for full
+    batches, eager for the ragged last one -- same epoch result and weights as the eager Trainer."""
+    from deepipr_amd.experiments.trainer import Trainer
+    outs = []
+    for graph in (False, True):
+        prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+        x, y = x.to(DEV), y.to(DEV)
+        loader = [(x, y), (x.flip(0), y.flip(0)), (x * 0.5, y), (x[:20], y[:20])]
+        opt = torch.optim.SGD(prod.parameters(), **SGD)
+        bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+        try:
+            res = Trainer(prod, opt, None, torch.device(DEV), graph=graph).train(1, loader)
+        finally:
+            torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+        outs.append((res, {k: v.clone() for k, v in prod.state_dict().items()}))
+    (re, se), (rg, sg) = outs
+    for k in ('loss', 'sign_loss', 'sign_acc', 'acc'):
+        assert re[k] == pytest.approx(rg[k], rel=1e-4, abs=1e-5), k
+    for k in se:
+        if se[k].dtype.is_floating_point:
+            assert torch.allclose(se[k], sg[k], rtol=1e-3, atol=1e-5), k
+        else:
+            assert torch.equal(se[k], sg[k]), k
+
+
+def test_entry_points_run_on_the_gpu(tmp_path, monkeypatch):
+    """train_v1.py (shuffle keys, hipGraph replay) and train_v23.py --train-backdoor end to end on synthetic data."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(root)
+    sys.path.insert(0, root)
+    import train_v1
+    import train_v23
+    out = train_v1.main(['--arch', 'resnet', '--train-passport', '--key-type', 'shuffle', '--epochs', '2',
+                         '--passport-config', 'passport_configs/resnet18_passport.json', '--batch-size', '64',
+                         '--synthetic-samples', '256', '--graph', '--logdir', str(tmp_path)])
+    h = out['history']
+    assert len(h) == 2 and all(np.isfinite(r['train_loss']) for r in h) and h[0]['train_sign_loss'] > 0
+    assert h[1]['train_sign_loss'] < h[0]['train_sign_loss']          # the hinge is being driven down
+    out = train_v23.main(['--arch', 'alexnet', '--train-backdoor', '--key-type', 'random', '--epochs', '1',
+                          '--batch-size', '32', '--synthetic-samples', '128', '--dataset', 'cifar100',
+                          '--logdir', str(tmp_path)])
+    assert 'valid_s_private_features.4' in out['history'][0]
+
+
 def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
