@@ -159,3 +159,41 @@ def test_passport_kwargs_builder_matches_reference_shape():
     kw, keys = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'gn', 'key_type': 'random',
                                                     'sl_ratio': 0.5}, need_index=True)
     assert keys == ['4', '5', '6'] and kw['4']['b'] == 'abc' and kw['4']['flag'] is True
+
+
+def _ckpt(gold, prefix):
+    return {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in gold.items() if k.startswith(prefix)}
+
+
+def test_reference_checkpoints_load_strictly_and_reproduce_outputs(golden_dir, cpu_kernels):
+    """state_dicts written by the REFERENCE's PassportBlock / PassportPrivateBlock load with
+    strict=True into fresh blocks of this build (lazily created key buffers included) and give the reference's
+    evaluation outputs."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
+    from tests.compare import close
+    gold = load_golden(golden_dir, 'blocks')
+    kw = {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1}
+    x = torch.from_numpy(gold['ckpt_in/x'])
+    sd = _ckpt(gold, 'ckpt_v1/')
+    assert set(sd) == {'weight', 'conv.weight', 'b', 'sign_loss.b', 'key', 'skey', 'bn.running_mean',
+                       'bn.running_var', 'bn.num_batches_tracked'}
+    for fuse in (True, False):
+        blk = PassportBlock(4, 16, 3, 1, 1, kw)
+        blk.fuse_norm = fuse
+        blk.load_state_dict(sd, strict=True)
+        blk.eval()
+        with torch.no_grad():
+            close(blk(x).numpy(), gold['ckpt_v1_out/y'], 'v1 eval output', 2e-5, 2e-6)
+    sd = _ckpt(gold, 'ckpt_private/')
+    assert {'scale', 'bias', 'key_private', 'skey_private', 'sign_loss_private.b'} <= set(sd)
+    blk = PassportPrivateBlock(4, 16, 3, 1, 1, kw)
+    blk.load_state_dict(sd, strict=True)
+    blk.eval()
+    with torch.no_grad():
+        close(blk(x, ind=0).numpy(), gold['ckpt_private_out/y0'], 'public eval output', 2e-5, 2e-6)
+        close(blk(x, ind=1).numpy(), gold['ckpt_private_out/y1'], 'private eval output', 2e-5, 2e-6)
+    # and the other direction: a state_dict written here has exactly the reference's key set
+    mine = PassportBlock(4, 16, 3, 1, 1, kw)
+    mine(x)
+    assert set(mine.state_dict()) == set(_ckpt(gold, 'ckpt_v1/'))

@@ -578,6 +578,31 @@ def test_entry_points_run_on_the_gpu(tmp_path, monkeypatch):
     assert 'valid_s_private_features.4' in out['history'][0]
 
 
+def test_reference_checkpoints_on_gpu(golden_dir):
+    """Reference-written state_dicts -> strict load -> .to(gpu) -> the reference's eval outputs (HIP kernels)."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
+    gold = load_golden(golden_dir, 'blocks')
+    kw = {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1}
+    x = dev(gold['ckpt_in/x'])
+    sd = {k[len('ckpt_v1/'):]: torch.from_numpy(np.array(v)) for k, v in gold.items() if k.startswith('ckpt_v1/')}
+    for fuse in (True, False):
+        blk = PassportBlock(4, 16, 3, 1, 1, kw)
+        blk.fuse_norm = fuse
+        blk.load_state_dict(sd, strict=True)
+        blk = blk.to(DEV).eval()
+        with torch.no_grad():
+            close(host(blk(x)), gold['ckpt_v1_out/y'], 'v1 eval', 1e-4, 1e-5)
+    sd = {k[len('ckpt_private/'):]: torch.from_numpy(np.array(v)) for k, v in gold.items()
+          if k.startswith('ckpt_private/')}
+    blk = PassportPrivateBlock(4, 16, 3, 1, 1, kw)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        close(host(blk(x, ind=0)), gold['ckpt_private_out/y0'], 'public eval', 1e-4, 1e-5)
+        close(host(blk(x, ind=1)), gold['ckpt_private_out/y1'], 'private eval', 1e-4, 1e-5)
+
+
 def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})

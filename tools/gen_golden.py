@@ -104,6 +104,36 @@ def block_cases():
     out['bk3/dW'] = blk.weight.grad.numpy().copy()
     out['bk3/dx'] = x.grad.numpy().copy()
 
+    # checkpoint compatibility: state_dicts written by the reference's blocks after one training
+    # forward (lazily created keys included), plus their evaluation-mode outputs on a fixed input
+    rs = np.random.RandomState(11)
+    xin = torch.from_numpy(rs.standard_normal((6, 4, 8, 8)).astype(np.float32))
+    kw = {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1}
+    torch.manual_seed(5)
+    np.random.seed(5)
+    v1 = PassportBlock(4, 16, 3, 1, 1, kw)
+    v1.train()
+    v1(xin)
+    v1.eval()
+    for k, v in v1.state_dict().items():
+        out['ckpt_v1/' + k] = v.numpy().copy()
+    with torch.no_grad():
+        out['ckpt_v1_out/y'] = v1(xin).numpy()
+    pv = PassportPrivateBlock(4, 16, 3, 1, 1, kw)
+    pv.train()
+    pv(xin, ind=0)
+    pv(xin, ind=1)
+    with torch.no_grad():
+        pv.scale.add_(0.3 * torch.randn(16))
+        pv.bias.add_(0.3 * torch.randn(16))
+    pv.eval()
+    for k, v in pv.state_dict().items():
+        out['ckpt_private/' + k] = v.numpy().copy()
+    with torch.no_grad():
+        out['ckpt_private_out/y0'] = pv(xin, ind=0).numpy()
+        out['ckpt_private_out/y1'] = pv(xin, ind=1).numpy()
+    out['ckpt_in/x'] = xin.numpy()
+
     # passport_selection is driven by python's `random` module
     cands = torch.arange(5 * 6 * 2 * 2, dtype=torch.float32).view(5, 6, 2, 2)
     random.seed(1234)
