@@ -100,6 +100,7 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
 
 
 def profile_enable(on):
+    """1 / True = reset and enable, 2 = resume without resetting the counters, 0 / False = pause."""
     check(lib().deepipr_profile_enable(int(on)), 'profile_enable')
 
 

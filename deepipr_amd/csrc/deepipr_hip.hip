@@ -1257,7 +1257,7 @@ const char *deepipr_last_error(void) { return g_err; }
 
 int deepipr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (on) {
+    if (on == 1) {                                   // 1 = start afresh, 2 = resume, 0 = pause
         for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) { g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; }
     }
     g_prof.on = on != 0;

@@ -29,7 +29,7 @@ def env_world():
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment.  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('DEEPIPR_FORCE_DDP') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -51,7 +51,7 @@ def check_keys_materialised(model):
 
 def broadcast_state(model, src=0):
     """Rank `src`'s parameters and buffers (weights, keys, signature bits, norm statistics) to every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return
     with torch.no_grad():
         seen = set()
@@ -67,19 +67,21 @@ def broadcast_state(model, src=0):
             m.invalidate_key_cache()
 
 
-def replicate(model, device, bucket_mb=BUCKET_MB):
+def replicate(model, device, bucket_mb=BUCKET_MB, static_graph=True):
     """Synchronise `model` with rank 0 and wrap it for data-parallel training.
 
     broadcast_buffers=False: after the one-time sync above the keys and signature bits never change, and
     norm running statistics stay per-rank exactly as under the reference's DataParallel (rank 0's are the
     ones that get saved)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    force = os.environ.get('DEEPIPR_FORCE_DDP') == '1'       # exercise the wrapped path on a single GPU
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model
     check_keys_materialised(model)
     broadcast_state(model, 0)
     ids = [device.index] if device.type == 'cuda' else None
     return torch.nn.parallel.DistributedDataParallel(
-        model, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb)
+        model, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
+        static_graph=static_graph)     # same parameters used every step: lets DDP skip per-iteration bookkeeping
 
 
 def max_over_ranks(value, device):
@@ -92,3 +94,8 @@ def max_over_ranks(value, device):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

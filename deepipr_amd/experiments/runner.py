@@ -143,7 +143,8 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
     passport = private or args['train_passport']
     if passport:
         install_keys(args, model, valid_loader, ncls, device, next(iter(train_loader))[0])
-    opt = torch.optim.SGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001)
+    opt = torch.optim.SGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001,
+                          fused=(device.type == 'cuda'))
     steps = lr_config[lr_config['type']]
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
     if private:

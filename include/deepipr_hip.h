@@ -56,7 +56,7 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_BN_BWD_REDUCE 13
 #define DEEPIPR_K_BN_AFFINE_BWD 14
 #define DEEPIPR_PROFILE_KERNELS 15
-int deepipr_profile_enable(int on);
+int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 
 /* ------------------------------------------------------------------ passport conv -> global pool
