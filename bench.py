@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph (1 GPU only)')
+    ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
     ap.add_argument('--ddp-static-graph', type=int, default=1, help='DistributedDataParallel(static_graph=...)')
     args = ap.parse_args()
 
@@ -189,14 +190,24 @@ def main():
     ys = [torch.randint(0, args.classes, (args.batch,), generator=g).to(device) for _ in range(nb)]
     model.train()
     elems = passport_elements(model, xs[0])                 # also materialises the random keys
+    # Data parallelism: FlatSGD by default (flat parameter / gradient / momentum buffers, two large RCCL
+    # all-reduces with the first one overlapped with backward, one fused HIP optimiser kernel); --ddp selects
+    # DistributedDataParallel + torch's fused SGD for comparison.
+    if args.ddp:
+        wrap = lambda m: D.replicate(m, device, static_graph=bool(args.ddp_static_graph))
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+    else:
+        D.check_keys_materialised(model)
+        D.broadcast_state(model, 0)
+        wrap = lambda m: m
+        from deepipr_amd.flat_sgd import FlatSGD
+        opt = FlatSGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     if args.scheme == 1:
-        net = D.replicate(model, device, static_graph=bool(args.ddp_static_graph))
+        net = wrap(model)
         step = lambda i: train_step_v1(net, opt, xs[i % nb], ys[i % nb])
     else:
-        net = D.replicate(DualBranch(model), device, static_graph=bool(args.ddp_static_graph))
+        net = wrap(DualBranch(model))
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
-    # torch's fused (single multi-tensor kernel) SGD: same update rule, 0.75 ms less host time per step
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
 
     if args.graph:
         assert world == 1, '--graph is single-GPU only'
@@ -245,6 +256,7 @@ def main():
                                'CIFAR%d 3x32x32, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                ('1' if args.scheme == 1 else '2 private', args.classes, args.batch),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
+                   'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
                    'passport_layers': len(elems), 'launch': 'hipGraph replay' if args.graph else 'eager'},
     }
     dom = 'bn_affine_bwd' if prof.get('bn_affine_bwd', (0, 0))[1] > 0 else 'affine_bwd'
@@ -260,7 +272,7 @@ def main():
                 us = max(1e-3, 1000.0 * ms / n - overhead_us)
                 kern[name] = {'avg_us': round(us, 3), 'launches': n,
                               'GBps': round(bpe * per_launch_elems / (us * 1e-6) / 1e9, 1)}
-        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials'):
+        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials', 'sgd'):
             ms, n = prof.get(name, (0, 0))
             if n:
                 kern[name] = {'avg_us': round(1000.0 * ms / n - overhead_us, 3), 'launches': n}

@@ -1162,6 +1162,42 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
     if (dW) write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);
 }
 
+
+// ============================================================================================
+// SGD with momentum and weight decay over one flat parameter buffer (experiments/classification.py:47-50:
+// optim.SGD(lr, momentum=0.9, weight_decay=1e-4); torch semantics: g += wd*p; buf = mu*buf + g; p -= lr*buf).
+// One streaming pass: reads p, g, buf and writes p, buf = 20 B per parameter.  `grad_scale` folds the
+// 1/world_size of a summed all-reduce into the same pass.
+// ============================================================================================
+__global__ __launch_bounds__(kThreads) void k_sgd_momentum_v4(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                              float4 *__restrict__ buf, size_t n4, float lr,
+                                                              float mu, float wd, float gs) {
+    const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += step) {
+        float4 pv = p[i], bv = buf[i];
+        const float4 gv = g[i];
+        float d;
+        d = fmaf(wd, pv.x, gs * gv.x); bv.x = fmaf(mu, bv.x, d); pv.x = fmaf(-lr, bv.x, pv.x);
+        d = fmaf(wd, pv.y, gs * gv.y); bv.y = fmaf(mu, bv.y, d); pv.y = fmaf(-lr, bv.y, pv.y);
+        d = fmaf(wd, pv.z, gs * gv.z); bv.z = fmaf(mu, bv.z, d); pv.z = fmaf(-lr, bv.z, pv.z);
+        d = fmaf(wd, pv.w, gs * gv.w); bv.w = fmaf(mu, bv.w, d); pv.w = fmaf(-lr, bv.w, pv.w);
+        p[i] = pv;
+        buf[i] = bv;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_sgd_momentum_s(float *__restrict__ p, const float *__restrict__ g,
+                                                             float *__restrict__ buf, size_t n, float lr, float mu,
+                                                             float wd, float gs) {
+    const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += step) {
+        const float d = fmaf(wd, p[i], gs * g[i]);
+        const float b = fmaf(mu, buf[i], d);
+        buf[i] = b;
+        p[i] = fmaf(-lr, b, p[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
@@ -1639,6 +1675,24 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                                static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C));
     }
     return check_launch("passport_bn_bwd(apply)");
+}
+
+
+int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
+                              float momentum, float weight_decay, float grad_scale, void *stream) {
+    if (!param || !grad || !momentum_buf || n == 0) return fail(DEEPIPR_EINVAL, "sgd_momentum_step: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_SGD, st);
+    if (n % 4 == 0 && aligned16(param) && aligned16(grad) && aligned16(momentum_buf)) {
+        const size_t n4 = n / 4;
+        DEEPIPR_LAUNCH(prof, k_sgd_momentum_v4, dim3(grid_for(n4)), dim3(kThreads), st, reinterpret_cast<float4 *>(param),
+                       reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(momentum_buf), n4, lr,
+                       momentum, weight_decay, grad_scale);
+    } else {
+        DEEPIPR_LAUNCH(prof, k_sgd_momentum_s, dim3(grid_for(n)), dim3(kThreads), st, param, grad, momentum_buf, n, lr,
+                       momentum, weight_decay, grad_scale);
+    }
+    return check_launch("sgd_momentum_step");
 }
 
 }  // extern "C"

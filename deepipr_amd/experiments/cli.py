@@ -40,6 +40,8 @@ def make_parser(private):
     p.add_argument('--device', default=None, help='cuda (default) | cpu (tests only: needs patched kernels)')
     p.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     p.add_argument('--logdir', default='logs')
+    p.add_argument('--ddp', action='store_true', default=False,
+                   help='DistributedDataParallel + torch SGD instead of the default FlatSGD data parallelism')
     p.add_argument('--graph', action='store_true', default=False,
                    help='replay the train step from a captured hipGraph (single GPU, pays off at small batches)')
     return p

@@ -42,8 +42,11 @@ class GraphedTrainStep:
                      for p in g['params']}
         mom = {id(p): optimizer.state[p]['momentum_buffer'].clone() for g in optimizer.param_groups
                for p in g['params'] if had_state[id(p)] and optimizer.state[p]['momentum_buffer'] is not None}
+        flat_buf = optimizer.flat_buf.clone() if hasattr(optimizer, 'flat_buf') else None     # FlatSGD momentum
         step_fn(model, optimizer, self.static_data, self.static_target)
         with torch.no_grad():
+            if flat_buf is not None:
+                optimizer.flat_buf.copy_(flat_buf)
             for k, v in base.state_dict().items():
                 v.copy_(saved[k])
             for g in optimizer.param_groups:

@@ -143,16 +143,29 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
     passport = private or args['train_passport']
     if passport:
         install_keys(args, model, valid_loader, ncls, device, next(iter(train_loader))[0])
-    opt = torch.optim.SGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001,
-                          fused=(device.type == 'cuda'))
+    # SGD(momentum .9, weight decay 1e-4) as experiments/classification.py:47-50.  Default: FlatSGD (flat buffers,
+    # bucketed RCCL all-reduce overlapped with backward, one fused HIP kernel); --ddp: DistributedDataParallel +
+    # torch's SGD.
     steps = lr_config[lr_config['type']]
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
-    if private:
-        net = D.replicate(DualBranch(model), device)
-        trainer = TrainerPrivate(net, opt, sched, device, graph=bool(args.get('graph')) and world == 1)
+    if args.get('ddp'):
+        opt = torch.optim.SGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001,
+                              fused=(device.type == 'cuda'))
+        wrap = lambda m: D.replicate(m, device)
     else:
-        net = D.replicate(model, device)
-        trainer = Trainer(net, opt, sched, device, graph=bool(args.get('graph')) and world == 1)
+        from deepipr_amd.flat_sgd import FlatSGD
+        if passport:
+            D.check_keys_materialised(model)
+        D.broadcast_state(model, 0)
+        opt = FlatSGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001)
+        wrap = lambda m: m
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
+    graph = bool(args.get('graph')) and world == 1
+    if private:
+        net = wrap(DualBranch(model))
+        trainer = TrainerPrivate(net, opt, sched, device, graph=graph)
+    else:
+        net = wrap(model)
+        trainer = Trainer(net, opt, sched, device, graph=graph)
 
     scheme = scheme_of(args, private)
     logdir = os.path.join(args.get('logdir') or 'logs', '%s_%s_v%d%s' % (

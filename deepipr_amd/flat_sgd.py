@@ -1,0 +1,165 @@
+"""FlatSGD: SGD(momentum, weight decay) + data-parallel gradient exchange on flat HBM buffers.
+
+The reference steps `optim.SGD(lr, momentum=0.9, weight_decay=1e-4)` (experiments/classification.py:47-50)
+and, on several GPUs, lets `nn.DataParallel` gather gradients onto GPU 0 (experiments/trainer.py:92-93).
+The stock MI355X replacement would be DistributedDataParallel + a multi-tensor optimiser; profiled on this
+workload that costs ~50 extra per-parameter copy/scale kernels and ~0.5 ms per 6.6 ms step.  This module is
+the MI355X-first form instead:
+
+  * every parameter is a view into ONE flat fp32 buffer, likewise gradients and momentum (62 tensors,
+    44.7 MB each for ResNet18): the optimiser step is a single streaming HIP kernel (20 B / parameter);
+  * gradients are exchanged as FEW, LARGE all-reduces (xGMI is point-to-point and per-link bound: large
+    messages, no per-tensor collectives): parameters are split into a few buckets in reverse layer order
+    (75 % of ResNet18's bytes sit in layer4, whose gradients are ready first); each bucket is packed with one
+    `cat` kernel and all-reduced on RCCL's stream as soon as its last gradient has been accumulated, i.e.
+    while the earlier layers are still back-propagating; only the small last bucket (2.7 MB) waits for step();
+  * one process per GPU; rank 0's parameters/buffers are broadcast once (distributed.broadcast_state).
+
+It is a torch.optim.Optimizer (param_groups, zero_grad, lr schedulers work unchanged) and goes wherever the
+reference passes its optimiser: `Trainer(model, FlatSGD(model.parameters(), lr=...), scheduler, device)`.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from deepipr_amd import passport_ops as P
+
+_ALIGN = 64            # floats: every parameter starts on a 256-byte boundary of the flat buffer
+
+
+class FlatSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=1e-4, bucket_fractions=(0.45, 0.8, 0.95),
+                 process_group=None):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # DEEPIPR_FORCE_DDP=1: run the bucketed exchange even in a world of one (single-GPU rehearsal of the N>1 path)
+        self.comm = self.world > 1 or (dist.is_initialized() and os.environ.get('DEEPIPR_FORCE_DDP') == '1')
+        plist = self.param_groups[0]['params']
+        if len(self.param_groups) != 1:
+            raise ValueError('FlatSGD keeps one parameter group (one lr / momentum / weight decay)')
+        dev = plist[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in plist):
+            raise ValueError('FlatSGD needs fp32 parameters on one device')
+        # reverse registration order ~ the order in which backward finishes gradients (last layers first)
+        order = list(reversed(plist))
+        offsets, total = [], 0
+        for p in order:
+            offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._slots = []
+        self._zero_pool = torch.zeros(_ALIGN, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(order, offsets):
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view                                     # the Parameter now lives in the flat buffer
+                self._slots.append((p, off))
+        # Buckets in gradient-ready order, cut where the cumulative size passes each fraction.  For ResNet18
+        # (reverse order: linear, layer4.1 42 %, layer4.0 33 %, layer3 19 %, rest 6 %) that is four all-reduces
+        # of 19 / 15 / 8.5 / 2.7 MB; every bucket but the last is launched from a gradient hook while earlier
+        # layers are still back-propagating, so only the small last one is exposed.
+        cuts, k = [], 0
+        if self.comm and len(order) > 1:
+            fr = sorted(f for f in bucket_fractions if 0.0 < f < 1.0)
+            for i, (p, off) in enumerate(self._slots):
+                acc = off + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                while k < len(fr) and acc >= fr[k] * total:
+                    if i + 1 < len(order) and (not cuts or cuts[-1] != i + 1):
+                        cuts.append(i + 1)
+                    k += 1
+        bounds = [0] + cuts + [len(order)]
+        self._buckets = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+        self._bucket_of = {}
+        for b, (lo, hi) in enumerate(self._buckets):
+            for i in range(lo, hi):
+                self._bucket_of[id(self._slots[i][0])] = b
+        self._pending = [hi - lo for lo, hi in self._buckets]
+        self._launched = [False] * len(self._buckets)
+        self._works = []
+        self._hooks = []
+        if self.comm and len(self._buckets) > 1:
+            for p, _ in self._slots[:self._buckets[-1][0]]:          # every bucket but the last
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ------------------------------------------------------------------ bucket plumbing
+    def _range(self, b):
+        lo, hi = self._buckets[b]
+        start = self._slots[lo][1]
+        last_p, last_off = self._slots[hi - 1]
+        end = last_off + (last_p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        return start, end
+
+    def _pack(self, b):
+        """Gradients of bucket b -> their slots of flat_grad with ONE cat kernel (alignment pads and parameters
+        that received no gradient are filled from a zero buffer)."""
+        lo, hi = self._buckets[b]
+        start, end = self._range(b)
+        pieces = []
+        for p, off in self._slots[lo:hi]:
+            n = p.numel()
+            pad = (n + _ALIGN - 1) // _ALIGN * _ALIGN - n
+            if p.grad is None:
+                pieces.append(self._zeros(n + pad))
+                continue
+            pieces.append(p.grad.reshape(-1))
+            if pad:
+                pieces.append(self._zeros(pad))
+        torch.cat(pieces, out=self.flat_grad[start:end])
+
+    def _zeros(self, n):
+        if self._zero_pool.numel() < n:
+            self._zero_pool = torch.zeros(n, dtype=torch.float32, device=self.flat_grad.device)
+        return self._zero_pool[:n]
+
+    def _launch(self, b, async_op):
+        self._pack(b)
+        self._launched[b] = True
+        if self.comm:
+            start, end = self._range(b)
+            w = dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self._works.append(w)
+
+    def _on_grad(self, param):
+        b = self._bucket_of[id(param)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b, async_op=True)           # overlaps with the rest of backward
+
+    # ------------------------------------------------------------------ optimiser interface
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for b in range(len(self._buckets)):
+            if not self._launched[b]:
+                self._launch(b, async_op=False)
+        for w in self._works:
+            w.wait()
+        g = self.param_groups[0]
+        P.kernels.sgd_momentum_step(self.flat_param, self.flat_grad, self.flat_buf, float(g['lr']),
+                                    float(g['momentum']), float(g['weight_decay']), 1.0 / self.world)
+        self._works = []
+        self._launched = [False] * len(self._buckets)
+        self._pending = [hi - lo for lo, hi in self._buckets]
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['flat_momentum'] = self.flat_buf.detach().cpu()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        buf = state_dict.pop('flat_momentum', None)
+        super().load_state_dict(state_dict)
+        if buf is not None:
+            self.flat_buf.copy_(buf.to(self.flat_buf.device))

@@ -242,6 +242,15 @@ class HipKernels:
         return dx, dw, dgb[0], dgb[1]
 
 
+    def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
+        """In-place SGD(momentum, weight decay) over flat fp32 buffers of equal length."""
+        dev = _chk(flat_param, flat_grad, flat_buf)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_sgd_momentum_step(_p(flat_param), _p(flat_grad), _p(flat_buf),
+                                                           flat_param.numel(), lr, momentum, weight_decay,
+                                                           grad_scale, _stream(dev)), 'sgd_momentum_step')
+
+
 kernels = HipKernels()
 
 

@@ -55,7 +55,8 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_BN_AFFINE_FWD 12
 #define DEEPIPR_K_BN_BWD_REDUCE 13
 #define DEEPIPR_K_BN_AFFINE_BWD 14
-#define DEEPIPR_PROFILE_KERNELS 15
+#define DEEPIPR_K_SGD 15
+#define DEEPIPR_PROFILE_KERNELS 16
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 
@@ -176,6 +177,17 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
                             void *stream);
+
+/* ------------------------------------------------------------------ optimiser step on flat buffers
+ * SGD with momentum and weight decay, torch.optim.SGD semantics (dampening 0, no Nesterov):
+ *     g = grad_scale*grad + weight_decay*param;  buf = momentum*buf + g;  param -= lr*buf
+ * over ONE flat buffer of n floats holding every parameter (20 B of traffic per parameter, one launch,
+ * instead of a multi-tensor loop over ~60 tensors).  grad_scale = 1/world_size folds the averaging of a summed
+ * all-reduce into the pass.  buf must be zero before the first step (torch then sets buf = g, the same value).
+ * replaces: optimizer.step() of experiments/trainer.py:145 with optim.SGD(lr, momentum=0.9,
+ *           weight_decay=1e-4) from experiments/classification.py:47-50. */
+int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
+                              float momentum, float weight_decay, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,9 @@ class OracleKernels:
             dg = dg + self.sign_loss_bwd(dloss, table[:, 2].contiguous(), b, alpha, margin, l2)
         dw = self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None
         return dx.float(), dw, dg, db
+
+    def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
+        with torch.no_grad():
+            d = flat_grad * grad_scale + weight_decay * flat_param
+            flat_buf.mul_(momentum).add_(d)
+            flat_param.add_(flat_buf, alpha=-lr)

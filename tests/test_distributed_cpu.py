@@ -50,7 +50,7 @@ def _batch():
     return torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
 
 
-def _worker(rank, world, port, private, out_dir):
+def _worker(rank, world, port, private, out_dir, flat=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
@@ -65,23 +65,35 @@ def _worker(rank, world, port, private, out_dir):
     assert (r, w) == (rank, world)
     model = _build(private, seed=100 + rank)       # different weights / keys / bits per rank before the sync
     dev = torch.device('cpu')
-    wrapped = D.replicate(DualBranch(model) if private else model, dev)
-    state0 = {k: v.clone() for k, v in model.state_dict().items()}
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    if flat:                                       # FlatSGD: no DDP wrapper, the optimiser exchanges the gradients
+        from deepipr_amd.flat_sgd import FlatSGD
+        D.check_keys_materialised(model)
+        D.broadcast_state(model, 0)
+        wrapped = DualBranch(model) if private else model
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        assert len(opt._buckets) >= 3 and opt.world == 2
+    else:
+        wrapped = D.replicate(DualBranch(model) if private else model, dev)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
     x, y = _batch()
     lo, hi = rank * 4, rank * 4 + 4
     step = train_step_v23 if private else train_step_v1
     out = step(wrapped, opt, x[lo:hi], y[lo:hi])
+    if flat:                                       # a second step exercises momentum and the bucket bookkeeping
+        out2 = step(wrapped, opt, x[lo:hi].flip(0), y[lo:hi].flip(0))
     torch.save({'state0': state0, 'state1': {k: v.clone() for k, v in model.state_dict().items()},
                 'sign_loss': float(out[1])}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('flat', [False, True])
 @pytest.mark.parametrize('private', [False, True])
-def test_two_rank_step_equals_single_process_step(private, tmp_path, monkeypatch):
+def test_two_rank_step_equals_single_process_step(private, flat, tmp_path, monkeypatch):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, private, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, private, str(tmp_path), flat), nprocs=2, join=True)
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     # (1) after replicate(): every rank holds rank 0's weights, keys and signature bits
@@ -109,6 +121,10 @@ def test_two_rank_step_equals_single_process_step(private, tmp_path, monkeypatch
     else:
         out = train_step_v1(model, opt, x, y)
     assert float(out[1]) == pytest.approx(r0['sign_loss'], rel=1e-5)
+    if flat:
+        xf = torch.cat([x[:4].flip(0), x[4:].flip(0)])
+        yf = torch.cat([y[:4].flip(0), y[4:].flip(0)])
+        (train_step_v23(DualBranch(model), opt, xf, yf) if private else train_step_v1(model, opt, xf, yf))
     single = model.state_dict()
     for k, v in r0['state1'].items():
         if v.dtype.is_floating_point:

@@ -534,12 +534,13 @@ def test_trainer_graph_mode_equals_eager_epoch():
     """Trainer(graph=True): captured on the first batch (without advancing training), replayed for full
     batches, eager for the ragged last one -- same epoch result and weights as the eager Trainer."""
     from deepipr_amd.experiments.trainer import Trainer
+    from deepipr_amd.flat_sgd import FlatSGD
     outs = []
-    for graph in (False, True):
+    for graph, flat in ((False, False), (True, False), (True, True)):
         prod, _ref, x, y = _fullsize_pair(False, 32, 10)
         x, y = x.to(DEV), y.to(DEV)
         loader = [(x, y), (x.flip(0), y.flip(0)), (x * 0.5, y), (x[:20], y[:20])]
-        opt = torch.optim.SGD(prod.parameters(), **SGD)
+        opt = (FlatSGD if flat else torch.optim.SGD)(prod.parameters(), **SGD)
         bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
         try:
@@ -547,14 +548,15 @@ def test_trainer_graph_mode_equals_eager_epoch():
         finally:
             torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
         outs.append((res, {k: v.clone() for k, v in prod.state_dict().items()}))
-    (re, se), (rg, sg) = outs
-    for k in ('loss', 'sign_loss', 'sign_acc', 'acc'):
-        assert re[k] == pytest.approx(rg[k], rel=1e-4, abs=1e-5), k
-    for k in se:
-        if se[k].dtype.is_floating_point:
-            assert torch.allclose(se[k], sg[k], rtol=1e-3, atol=1e-5), k
-        else:
-            assert torch.equal(se[k], sg[k]), k
+    (re, se) = outs[0]
+    for (rg, sg) in outs[1:]:
+        for k in ('loss', 'sign_loss', 'sign_acc', 'acc'):
+            assert re[k] == pytest.approx(rg[k], rel=1e-4, abs=1e-5), k
+        for k in se:
+            if se[k].dtype.is_floating_point:
+                assert torch.allclose(se[k], sg[k], rtol=1e-3, atol=1e-5), k
+            else:
+                assert torch.equal(se[k], sg[k]), k
 
 
 def test_entry_points_run_on_the_gpu(tmp_path, monkeypatch):
@@ -601,6 +603,39 @@ def test_reference_checkpoints_on_gpu(golden_dir):
     with torch.no_grad():
         close(host(blk(x, ind=0)), gold['ckpt_private_out/y0'], 'public eval', 1e-4, 1e-5)
         close(host(blk(x, ind=1)), gold['ckpt_private_out/y1'], 'private eval', 1e-4, 1e-5)
+
+
+def test_flat_sgd_equals_torch_sgd_on_gpu(K):
+    """FlatSGD (flat buffers + the fused HIP SGD kernel) against torch.optim.SGD over four train steps, and the
+    kernel alone against the update rule in float64."""
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.flat_sgd import FlatSGD
+    rs = np.random.RandomState(0)
+    n = 1000003                                              # odd length: scalar tail path
+    p0, g0, b0 = [rs.standard_normal(n).astype(np.float32) for _ in range(3)]
+    for nn in (n, 1 << 20):
+        p, g, b = dev(p0[:nn]), dev(g0[:nn]), dev(b0[:nn])
+        K.sgd_momentum_step(p, g, b, 0.05, 0.9, 1e-4, 0.5)
+        d = 0.5 * g0[:nn].astype(np.float64) + 1e-4 * p0[:nn]
+        bw = 0.9 * b0[:nn] + d
+        close(host(b), bw, 'momentum buffer', 1e-6, 1e-6)
+        close(host(p), p0[:nn] - 0.05 * bw, 'parameter', 1e-6, 1e-6)
+    finals = []
+    bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    try:
+        for flat in (False, True):
+            prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+            x, y = x.to(DEV), y.to(DEV)
+            opt = (FlatSGD if flat else torch.optim.SGD)(prod.parameters(), **SGD)
+            for i in range(4):
+                train_step_v1(prod, opt, x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+            finals.append({k: v.clone() for k, v in prod.state_dict().items()})
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+    for k in finals[0]:
+        if finals[0][k].dtype.is_floating_point:
+            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
 
 
 def test_product_has_no_cpu_path():
