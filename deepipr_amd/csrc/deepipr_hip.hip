@@ -499,10 +499,20 @@ struct BwdPlan {
 
 BwdPlan plan_bwd(int N, int C, int P, bool can_vec) {
     BwdPlan p;
-    p.VEC = (can_vec && P % 4 == 0) ? 4 : 1;
-    const int pu = P / p.VEC;
-    p.large = pu > kThreads;
-    if (!p.large) {
+    // float4 units need every row start (n*C + c0)*P to be a multiple of 4 floats: true when P % 4 == 0, or --
+    // 7x7 / 9x9 ... maps -- when C % 4 == 0 and tiles are 4 channels (a unit may then straddle two channels,
+    // which the kernels handle per element)
+    const bool odd_plane_vec = can_vec && P % 4 != 0 && C % 4 == 0 && P <= kThreads;
+    p.VEC = (can_vec && (P % 4 == 0 || odd_plane_vec)) ? 4 : 1;
+    const int pu = (P % 4 == 0 || p.VEC == 1) ? P / p.VEC : 0;      // units per plane (0: planes share units)
+    p.large = !odd_plane_vec && pu > kThreads;
+    if (odd_plane_vec) {
+        p.CT = 4;
+        p.row_u = P;                                                // 4 planes = P float4 units
+        p.npi = kThreads / p.row_u;
+        p.tiles = C / 4;
+        p.iters = (N + p.npi - 1) / p.npi;
+    } else if (!p.large) {
         int ct = (64 + P - 1) / P;                      // rows of >= 256 B
         if (ct < 1) ct = 1;
         if (ct > C) ct = C;
@@ -1115,6 +1125,84 @@ __global__ __launch_bounds__(kThreads) void k_bn_affine_bwd_s(
     }
 }
 
+
+// ---- float4 streaming passes for planes that are not a multiple of 4 floats (7x7 maps): the channel is
+// ---- resolved per element (a float4 can straddle two planes); needs only total % 4 == 0.
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_affine_fwd_v4g(
+    const float4 *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float4 *__restrict__ y, unsigned n4, FastDiv pdiv, FastDiv cdiv, unsigned C, int with_sign, SignArgs sa) {
+    __shared__ double red[12];
+    unsigned nblk = gridDim.x;
+    if (with_sign) {
+        nblk -= 1;
+        if (blockIdx.x == nblk) {
+            sign_loss_block(gamma, sa.b, sa.alpha, sa.margin, sa.l2, static_cast<int>(C), sa.loss, sa.acc,
+                            sa.bits, red);
+            return;
+        }
+    }
+    const unsigned step = nblk * kThreads;
+    for (unsigned q = blockIdx.x * kThreads + threadIdx.x; q < n4; q += step) {
+        const float4 v = x[q];
+        float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned plane = fdiv(4 * q + i, pdiv);
+            const unsigned c = plane - fdiv(plane, cdiv) * C;
+            out[i] = affine1<RELU>(in[i], gamma[c], beta[c]);
+        }
+        y[q] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_fwd_v4g(
+    const float4 *__restrict__ x, const float *__restrict__ tbl, float4 *__restrict__ y, unsigned n4, FastDiv pdiv,
+    FastDiv cdiv, unsigned C, int with_sign, SignArgs sa, const float *__restrict__ gamma) {
+    __shared__ double red[12];
+    unsigned nblk = gridDim.x;
+    if (with_sign) {
+        nblk -= 1;
+        if (blockIdx.x == nblk) {
+            sign_loss_block(gamma, sa.b, sa.alpha, sa.margin, sa.l2, static_cast<int>(C), sa.loss, sa.acc,
+                            sa.bits, red);
+            return;
+        }
+    }
+    const unsigned step = nblk * kThreads;
+    for (unsigned q = blockIdx.x * kThreads + threadIdx.x; q < n4; q += step) {
+        const float4 v = x[q];
+        float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned plane = fdiv(4 * q + i, pdiv);
+            const unsigned c = plane - fdiv(plane, cdiv) * C;
+            out[i] = bn_affine1<RELU>(in[i], *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl));
+        }
+        y[q] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_affine_bwd_v4g(
+    const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
+    float4 *__restrict__ dx, unsigned n4, FastDiv pdiv, FastDiv cdiv, unsigned C) {
+    const unsigned step = gridDim.x * kThreads;
+    for (unsigned q = blockIdx.x * kThreads + threadIdx.x; q < n4; q += step) {
+        const float4 d = dy[q], v = x[q];
+        float din[4] = {d.x, d.y, d.z, d.w}, xin[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned plane = fdiv(4 * q + i, pdiv);
+            const unsigned c = plane - fdiv(plane, cdiv) * C;
+            const float4 *t = reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c) * kTbl);
+            out[i] = bn_bwd1<RELU>(din[i], xin[i], t[0], t[1]);
+        }
+        dx[q] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 // Finish of the fused backward: as k_passport_bwd_finish plus the table for the apply pass.
 // W-less form (dW == nullptr, s == nullptr) serves the public branch with learnable gamma/beta.
 struct BnBwdFinishArgs {
@@ -1227,6 +1315,18 @@ int launch_affine_fwd(const float *xhat, const float *gamma, const float *beta, 
             DEEPIPR_LAUNCH(prof, k_affine_fwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(xhat), gamma, beta,
                                reinterpret_cast<float4 *>(y), n4, pdiv, cdiv, static_cast<unsigned>(C),
                                with_sign ? 1 : 0, sa);
+    } else if (total % 4 == 0 && aligned16(xhat) && aligned16(y)) {
+        const unsigned n4 = static_cast<unsigned>(total / 4);
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
+        const int grid = grid_for(n4) + (with_sign ? 1 : 0);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_v4g<true>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(xhat), gamma, beta, reinterpret_cast<float4 *>(y), n4,
+                           pdiv, cdiv, static_cast<unsigned>(C), with_sign ? 1 : 0, sa);
+        else
+            DEEPIPR_LAUNCH(prof, k_affine_fwd_v4g<false>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(xhat), gamma, beta, reinterpret_cast<float4 *>(y), n4,
+                           pdiv, cdiv, static_cast<unsigned>(C), with_sign ? 1 : 0, sa);
     } else {
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
         const int grid = grid_for(total) + (with_sign ? 1 : 0);
@@ -1604,6 +1704,18 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
         else
             DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(x), table, reinterpret_cast<float4 *>(y), n4, pdiv,
                                cdiv, static_cast<unsigned>(C), with_sign ? 1 : 0, sa, g_for_sign);
+    } else if (total % 4 == 0 && aligned16(x) && aligned16(y)) {
+        const unsigned n4 = static_cast<unsigned>(total / 4);
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
+        const int grid = grid_for(n4) + (with_sign ? 1 : 0);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_v4g<true>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(x), table, reinterpret_cast<float4 *>(y), n4, pdiv, cdiv,
+                           static_cast<unsigned>(C), with_sign ? 1 : 0, sa, g_for_sign);
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_fwd_v4g<false>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(x), table, reinterpret_cast<float4 *>(y), n4, pdiv, cdiv,
+                           static_cast<unsigned>(C), with_sign ? 1 : 0, sa, g_for_sign);
     } else {
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
         const int grid = grid_for(total) + (with_sign ? 1 : 0);
@@ -1664,6 +1776,18 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
         else
             DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_v4<false>, dim3(grid), dim3(kThreads), st, reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x), table_out,
                                reinterpret_cast<float4 *>(dx), n4, pdiv, cdiv, static_cast<unsigned>(C));
+    } else if (total % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx)) {
+        const unsigned n4 = static_cast<unsigned>(total / 4);
+        const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
+        const int grid = grid_for(n4);
+        if (relu)
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_v4g<true>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x), table_out,
+                           reinterpret_cast<float4 *>(dx), n4, pdiv, cdiv, static_cast<unsigned>(C));
+        else
+            DEEPIPR_LAUNCH(prof, k_bn_affine_bwd_v4g<false>, dim3(grid), dim3(kThreads), st,
+                           reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x), table_out,
+                           reinterpret_cast<float4 *>(dx), n4, pdiv, cdiv, static_cast<unsigned>(C));
     } else {
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW));
         const int grid = grid_for(total);

@@ -47,6 +47,9 @@ AFFINE_SHAPES = [
     (1, 1, 1, 1),         # degenerate
     (7, 10, 2, 2),        # partial channel tiles
     (130, 20, 1, 1),      # HW = 1 (fully-connected style)
+    (16, 64, 7, 7),       # ImageNet layer4 maps: float4 units straddling channels (C % 4 == 0)
+    (4, 8, 9, 9),         # 9x9 planes, 81 floats
+    (3, 12, 15, 15),      # 225-float planes, 4-channel tiles
 ]
 
 
@@ -222,7 +225,7 @@ def test_fused_layer_equals_unfused(K, shape, with_sign):
 
 # ----------------------------------------------------------------------------- BatchNorm-fused layer
 BN_SHAPES = [(128, 512, 4, 4, 4608), (64, 384, 8, 8, 1728), (6, 64, 32, 32, 27), (3, 16, 56, 56, 144),
-             (5, 24, 7, 7, 75), (2, 3, 5, 3, 12), (9, 10, 2, 2, 40)]
+             (5, 24, 7, 7, 75), (2, 3, 5, 3, 12), (9, 10, 2, 2, 40), (16, 64, 7, 7, 576), (4, 8, 9, 9, 72)]
 
 
 @pytest.mark.parametrize('mode', ['passport', 'passport_nosign', 'public', 'eval'])
