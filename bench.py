@@ -44,15 +44,25 @@ BYTES_PER_ELT = {'bn_affine_bwd': 12, 'bn_affine_fwd': 8, 'bn_bwd_reduce': 8, 'b
 
 
 def build_model(args, device):
+    if getattr(args, 'arch', 'resnet18') == 'alexnet':
+        from deepipr_amd.models.alexnet_passport import AlexNetPassport
+        from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+        cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'alexnet_passport.json')))
+        kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                                  'sl_ratio': 0.1})
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cls = AlexNetPassport if args.scheme == 1 else AlexNetPassportPrivate
+        return cls(3, args.classes, kw, imagenet=getattr(args, 'image_size', 32) > 32).to(device)
     cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
     kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
                                               'sl_ratio': 0.1})
     torch.manual_seed(0)
     np.random.seed(0)
     if args.scheme == 1:
-        model = ResNet18Passport(num_classes=args.classes, passport_kwargs=kw)
+        model = ResNet18Passport(num_classes=args.classes, passport_kwargs=kw, imagenet=getattr(args, 'image_size', 32) > 32)
     else:
-        model = ResNet18Private(num_classes=args.classes, passport_kwargs=kw)
+        model = ResNet18Private(num_classes=args.classes, passport_kwargs=kw, imagenet=getattr(args, 'image_size', 32) > 32)
     return model.to(device)
 
 
@@ -85,7 +95,9 @@ def host_cores():
 def cpu_baseline(args, budget_s=20.0):
     """The oracle's plain-PyTorch CPU step on the same workload, bounded to ~budget_s seconds."""
     from oracle import torch_ref
-    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
+    arch = getattr(args, 'arch', 'resnet18')
+    hw = getattr(args, 'image_size', 32)
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', '%s_passport.json' % arch)))
     kw = torch_ref.passport_kwargs_from_config(cfg, 'bn', 'random', 0.1)
     torch.manual_seed(0)
     np.random.seed(0)
@@ -93,10 +105,14 @@ def cpu_baseline(args, budget_s=20.0):
     # quota 16; running oneDNN on all 256 visible threads took 75 s per step).
     threads = int(os.environ.get('DEEPIPR_CPU_THREADS', host_cores()))
     torch.set_num_threads(threads)
-    model = torch_ref.resnet18_ref(num_classes=args.classes, passport_kwargs=kw, private=args.scheme != 1)
+    if arch == 'alexnet':
+        model = torch_ref.AlexNetRef(3, args.classes, kw, private=args.scheme != 1)
+    else:
+        model = torch_ref.resnet18_ref(num_classes=args.classes, passport_kwargs=kw, private=args.scheme != 1,
+                                       imagenet=hw > 32)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(args.batch, 3, 32, 32, generator=g)
+    x = torch.randn(args.batch, 3, hw, hw, generator=g)
     y = torch.randint(0, args.classes, (args.batch,), generator=g)
     step = torch_ref.v1_step if args.scheme == 1 else torch_ref.v23_step
     model.train()
@@ -165,6 +181,8 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
     ap.add_argument('--scheme', type=int, default=1, choices=[1, 2])
     ap.add_argument('--classes', type=int, default=10)
+    ap.add_argument('--arch', default='resnet18', choices=['resnet18', 'alexnet'])
+    ap.add_argument('--image-size', type=int, default=32, help='32 = CIFAR shapes, 224 = ImageNet shapes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
@@ -186,7 +204,8 @@ def main():
     model = build_model(args, device)
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     nb = 4                                                  # distinct synthetic batches, resident in HBM
-    xs = [torch.randn(args.batch, 3, 32, 32, generator=g).to(device) for _ in range(nb)]
+    hw = args.image_size
+    xs = [torch.randn(args.batch, 3, hw, hw, generator=g).to(device) for _ in range(nb)]
     ys = [torch.randint(0, args.classes, (args.batch,), generator=g).to(device) for _ in range(nb)]
     model.train()
     elems = passport_elements(model, xs[0])                 # also materialises the random keys
@@ -248,13 +267,18 @@ def main():
     value = args.gpus * args.batch * args.steps / dt
     fwd_per_step = 1 if args.scheme == 1 else 2
     out = {
-        'metric': 'images/sec ResNet18-passport CIFAR10 train step', 'value': round(value, 1), 'unit': 'img/s',
+        'metric': 'images/sec %s-passport %s train step' % (
+            'ResNet18' if args.arch == 'resnet18' else 'AlexNet',
+            'CIFAR%d' % args.classes if args.image_size == 32 else 'ImageNet-shape'),
+        'value': round(value, 1), 'unit': 'img/s',
         'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'ResNet18 V%s passport (resnet18_passport.json: 5 layer4 passport layers), '
-                               'CIFAR%d 3x32x32, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
-                               ('1' if args.scheme == 1 else '2 private', args.classes, args.batch),
+        'config': {'workload': '%s V%s passport (%s_passport.json: %d passport layers), '
+                               '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
+                               ('ResNet18' if args.arch == 'resnet18' else 'AlexNet',
+                                '1' if args.scheme == 1 else '2 private', args.arch, len(elems), args.classes,
+                                args.image_size, args.image_size, args.batch),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
                    'passport_layers': len(elems), 'launch': 'hipGraph replay' if args.graph else 'eager'},
@@ -281,11 +305,11 @@ def main():
                                dom, 'norm+affine' if dom.startswith('bn') else 'affine'),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
-                           'traffic': pmc_traffic('k_' + dom, 'R[%d,512,4,4]' % args.batch),
+                           'traffic': pmc_traffic('k_' + dom, 'R[%d,512,4,4]' % args.batch)
+                           if (args.arch, args.image_size) == ('resnet18', 32) else None,
                            'bytes_per_launch': int(12 * per_launch_elems), 'avg_us': a['avg_us'],
-                           'note': '12 B/elt x %d elts per launch; tensors are %.1f MB (L2/MALL-resident, '
-                                   'launch-latency bound at this shape)' % (per_launch_elems,
-                                                                           4 * per_launch_elems / 1e6)}
+                           'note': '12 B/elt x %d elts per launch (mean over the passport layers); tensors are '
+                                   '%.1f MB' % (per_launch_elems, 4 * per_launch_elems / 1e6)}
         out['kernels'] = kern
         if args.gpus == 1 and not args.no_stress:
             out['roofline_stress'] = stress_roofline(device)
