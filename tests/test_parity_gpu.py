@@ -404,7 +404,7 @@ def test_product_equals_stock_aten_on_gpu(private, fuse_norm):
         (lp + sp).backward()
         (lr + sr).backward()
         # Gradients.  An activation that sits within fp32 rounding of a ReLU kink may be masked differently by
-        # two correct implementations (tools/debug_hooks.py found exactly ONE such element of 2.6 M in the
+        # two correct implementations (tests/triage/debug_hooks.py found exactly ONE such element of 2.6 M in the
         # private case: one flipped mask => 21 % of max|dx| at that element, 2e-2 on the 4608 weights of its
         # output channel, ~1e-3 on everything upstream).  So: 99 % of every gradient's elements within 5e-3
         # of its scale, and no element further than what a couple of flips can explain.

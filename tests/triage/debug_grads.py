@@ -1,7 +1,7 @@
 """Gradient discrepancy triage on the GPU: stock ATen (twice), product unfused, product fused."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import patterns, torch_ref
 from oracle.cases import ALPHA, resnet18_config
