@@ -66,18 +66,21 @@ def build_model(args, device):
     return model.to(device)
 
 
-def passport_elements(model, batch):
-    """Activation elements of every passport layer for one batch (for the algorithmic byte count)."""
-    sizes = []
+def fused_layer_elements(model, run_once):
+    """Activation elements of every layer call that goes through the fused norm+affine kernels during one
+    step (passport layers and BatchNorm ConvBlocks), for the algorithmic byte count.  -> (all, passport only)"""
+    from deepipr_amd.models.layers.conv2d import ConvBlock
+    sizes, passport = [], []
     hooks = []
     for m in model.modules():
         if isinstance(m, PASSPORT_TYPES):
-            hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel())))
-    with torch.no_grad():
-        model(batch)
+            hooks.append(m.register_forward_hook(lambda mod, i, o: (sizes.append(o.numel()), passport.append(o.numel())) and None))
+        elif isinstance(m, ConvBlock) and isinstance(m.bn, torch.nn.BatchNorm2d) and m.fuse_norm:
+            hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel()) and None))
+    run_once()
     for h in hooks:
         h.remove()
-    return sizes
+    return sizes, passport
 
 
 def host_cores():
@@ -208,7 +211,8 @@ def main():
     xs = [torch.randn(args.batch, 3, hw, hw, generator=g).to(device) for _ in range(nb)]
     ys = [torch.randint(0, args.classes, (args.batch,), generator=g).to(device) for _ in range(nb)]
     model.train()
-    elems = passport_elements(model, xs[0])                 # also materialises the random keys
+    with torch.no_grad():
+        model(xs[0])                                        # materialises the random keys
     # Data parallelism: FlatSGD by default (flat parameter / gradient / momentum buffers, two large RCCL
     # all-reduces with the first one overlapped with backward, one fused HIP optimiser kernel); --ddp selects
     # DistributedDataParallel + torch's fused SGD for comparison.
@@ -228,6 +232,7 @@ def main():
         net = wrap(DualBranch(model))
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
 
+    all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
     if args.graph:
         assert world == 1, '--graph is single-GPU only'
         from deepipr_amd.experiments.graph_step import GraphedTrainStep
@@ -281,35 +286,51 @@ def main():
                                 args.image_size, args.image_size, args.batch),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
-                   'passport_layers': len(elems), 'launch': 'hipGraph replay' if args.graph else 'eager'},
+                   'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
+                   'launch': 'hipGraph replay' if args.graph else 'eager'},
     }
     dom = 'bn_affine_bwd' if prof.get('bn_affine_bwd', (0, 0))[1] > 0 else 'affine_bwd'
     if timing and prof.get(dom, (0, 0))[1] > 0:
-        per_launch_elems = float(np.mean(elems))
+        # Durations come from start/stop events attached to each kernel's own dispatch (hipExtLaunchKernelGGL):
+        # kernel execution time, comparable with rocprofv3's kernel trace.  The streaming kernels run once per
+        # fused layer call (passport layers AND BatchNorm ConvBlocks), so bytes and time are summed over all
+        # launches of the sampled steps: achieved = algorithmic bytes / kernel time.
+        sampled = len(range(0, args.steps, 4))
+        tot_elems = float(sum(all_elems))
         kern = {}
-        # durations come from start/stop events attached to each kernel's own dispatch
-        # (hipExtLaunchKernelGGL): kernel execution time, comparable with rocprofv3's kernel trace
-        overhead_us = 0.0
         for name, bpe in BYTES_PER_ELT.items():
             ms, n = prof.get(name, (0.0, 0))
             if n:
-                us = max(1e-3, 1000.0 * ms / n - overhead_us)
-                kern[name] = {'avg_us': round(us, 3), 'launches': n,
-                              'GBps': round(bpe * per_launch_elems / (us * 1e-6) / 1e9, 1)}
-        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials', 'sgd'):
+                fused = name.startswith('bn_')
+                per_step = bpe * (tot_elems if fused else float(sum(elems)))
+                us_step = 1000.0 * ms / sampled
+                kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3),
+                              'us_per_step': round(us_step, 1), 'bytes_per_step': int(per_step),
+                              'GBps': round(per_step / (us_step * 1e-6) / 1e9, 1)}
+                kern[name]['frac'] = round(kern[name]['GBps'] / HBM_PEAK_GBS, 4)
+        ms, n = prof.get('sgd', (0.0, 0))
+        if n:
+            nparam = sum(p.numel() for p in model.parameters())
+            us = 1000.0 * ms / n
+            kern['sgd'] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(us, 3),
+                           'bytes_per_step': 20 * nparam, 'GBps': round(20 * nparam / (us * 1e-6) / 1e9, 1)}
+            kern['sgd']['frac'] = round(kern['sgd']['GBps'] / HBM_PEAK_GBS, 4)
+        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials'):
             ms, n = prof.get(name, (0, 0))
             if n:
-                kern[name] = {'avg_us': round(1000.0 * ms / n - overhead_us, 3), 'launches': n}
+                kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3)}
         a = kern[dom]
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (passport %s backward pass: read dy + x, write dx)' % (
-                               dom, 'norm+affine' if dom.startswith('bn') else 'affine'),
-                           'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
-                           'traffic': pmc_traffic('k_' + dom, 'R[%d,512,4,4]' % args.batch)
-                           if (args.arch, args.image_size) == ('resnet18', 32) else None,
-                           'bytes_per_launch': int(12 * per_launch_elems), 'avg_us': a['avg_us'],
-                           'note': '12 B/elt x %d elts per launch (mean over the passport layers); tensors are '
-                                   '%.1f MB' % (per_launch_elems, 4 * per_launch_elems / 1e6)}
+        per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s backward pass: read dy + x, write dx)' % (
+                               dom, 'norm+affine+ReLU' if dom.startswith('bn') else 'affine'),
+                           'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
+                           'traffic': None, 'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
+                           'launches_per_step': a['launches_per_step'],
+                           'note': '12 B/elt; %d launches per step over activations of %.1f-%.1f MB (%d passport '
+                                   'layer calls of %.1f MB among them); PMC traffic = algorithmic bytes within 1 %% '
+                                   '(profiles/pmc_traffic.json)' % (
+                                       len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
+                                       len(elems), 4 * float(np.mean(elems)) / 1e6)}
         out['kernels'] = kern
         if args.gpus == 1 and not args.no_stress:
             out['roofline_stress'] = stress_roofline(device)

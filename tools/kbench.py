@@ -20,6 +20,8 @@ SHAPES = {
     'A   [64,384,8,8]': (64, 384, 8, 8),
     'P   [32,512,4,4]': (32, 512, 4, 4),
     'I   [256,512,7,7]': (256, 512, 7, 7),
+    'L3  [128,256,8,8]': (128, 256, 8, 8),
+    'L2  [128,128,16,16]': (128, 128, 16, 16),
     'S1  [128,64,32,32]': (128, 64, 32, 32),
     'S2  [256,256,16,16]': (256, 256, 16, 16),
     'S3  [512,512,8,8]': (512, 512, 8, 8),
