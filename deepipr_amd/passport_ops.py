@@ -300,11 +300,14 @@ class _AffineReLU(torch.autograd.Function):
         y = kernels.affine_relu_fwd(xhat, gamma, beta, relu)
         ctx.save_for_backward(xhat, gamma, beta)
         ctx.relu = relu
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xhat, gamma, beta = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None
         dx, dg, db = kernels.affine_relu_bwd(dy.contiguous(), xhat, gamma, beta, ctx.relu)
         return dx, dg, db, None
 
@@ -318,12 +321,15 @@ class _GammaBeta(torch.autograd.Function):
         gamma, beta = kernels.gamma_beta_fwd(weight, m)
         ctx.save_for_backward(weight, m)
         ctx.geom = (tuple(key.shape), stride, pad)
+        ctx.set_materialize_grads(False)
         return gamma, beta
 
     @staticmethod
     def backward(ctx, dgamma, dbeta):
         weight, m = ctx.saved_tensors
         key_shape, stride, pad = ctx.geom
+        if dgamma is None and dbeta is None:
+            return None, None, None, None, None, None
         zeros = None
         if dgamma is None or dbeta is None:
             zeros = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device)
@@ -344,11 +350,14 @@ class _SignLoss(torch.autograd.Function):
         ctx.save_for_backward(gamma, b)
         ctx.cfg = (float(alpha), float(l2))
         ctx.mark_non_differentiable(acc, bits)
+        ctx.set_materialize_grads(False)
         return loss, acc, bits
 
     @staticmethod
     def backward(ctx, dloss, _dacc, _dbits):
         gamma, b = ctx.saved_tensors
+        if dloss is None:
+            return None, None, None, None
         alpha, l2 = ctx.cfg
         return kernels.sign_loss_bwd(dloss.contiguous(), gamma, b, alpha, MARGIN, l2), None, None, None
 
@@ -367,9 +376,10 @@ class _PassportLayer(torch.autograd.Function):
         y, gamma, beta, loss, acc, bits = kernels.passport_fwd(xhat, weight, m, bb, float(alpha), relu)
         ctx.save_for_backward(xhat, weight, gamma, beta, m, bb)
         ctx.cfg = (float(alpha), relu, stride, pad, tuple(key.shape))
+        ctx.set_materialize_grads(False)
         if bb is None:
-            loss = acc = xhat.new_zeros(())
-            bits = torch.zeros(0, dtype=torch.int8, device=xhat.device)
+            loss = acc = xhat.new_empty(0)
+            bits = torch.empty(0, dtype=torch.int8, device=xhat.device)
         ctx.mark_non_differentiable(acc, bits)
         return y, gamma, beta, loss, acc, bits
 
@@ -408,12 +418,13 @@ class _PassportBNLayer(torch.autograd.Function):
             training)
         ctx.save_for_backward(x, w, table, m, bb)
         ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as freshly filled zeros
         # running_mean / running_var / num_batches_tracked are plain buffers updated in place by the kernel
         if gamma is None:
-            gamma = beta = x.new_zeros(0)
+            gamma = beta = x.new_empty(0)             # placeholders (no kernel): the public branch has no gamma
         if loss is None:
-            loss = acc = x.new_zeros(())
-            bits = torch.zeros(0, dtype=torch.int8, device=x.device)
+            loss = acc = x.new_empty(0)
+            bits = torch.empty(0, dtype=torch.int8, device=x.device)
         ctx.mark_non_differentiable(acc, bits)
         return y, gamma, beta, loss, acc, bits
 
