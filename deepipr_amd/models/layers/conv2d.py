@@ -10,6 +10,11 @@ import torch
 import torch.nn as nn
 
 
+# Below ~1 M activation elements (4 MB) the six-launch fused pipeline is launch-bound and MIOpen's single-kernel
+# batch norm + ATen ReLU are as fast on the GPU and cheaper on the host (measured: ResNet18 V2 at 32 images/GPU).
+FUSE_MIN_ELEMENTS = 1 << 20
+
+
 def make_norm(norm_type, channels, affine):
     """'bn' | 'gn' (channels // 16 groups) | 'in' | anything else -> no norm.
     models/layers/conv2d.py:15-22 and models/layers/passportconv2d.py:56-64."""
@@ -36,8 +41,8 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
-        if (self.fuse_norm and x.is_cuda and isinstance(self.bn, nn.BatchNorm2d) and self.bn.affine
-                and self.bn.momentum is not None and x.dtype == torch.float32):
+        if (self.fuse_norm and x.is_cuda and x.numel() >= FUSE_MIN_ELEMENTS and isinstance(self.bn, nn.BatchNorm2d)
+                and self.bn.affine and self.bn.momentum is not None and x.dtype == torch.float32):
             from deepipr_amd import passport_ops as P
             return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None)
         if self.bn is not None:

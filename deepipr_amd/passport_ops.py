@@ -192,6 +192,20 @@ class HipKernels:
         return dx, dw, dgb[0], dgb[1]
 
 
+    # Scratch that is written and consumed inside one call (partial sums, the backward channel table) is kept in
+    # a per-(device, stream) arena instead of being allocated per call: on one stream, calls are ordered, so
+    # reuse is safe (also inside a captured hipGraph, which replays the same order).  Saves three allocator
+    # round-trips per layer call on the host.
+    _arena = {}
+
+    def _scratch(self, dev, stream, nbytes):
+        key = (dev.index, stream)
+        buf = self._arena.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+            self._arena[key] = buf
+        return buf.data_ptr()
+
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
                         momentum, eps, training, margin=MARGIN, l2=L2):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x.
@@ -200,27 +214,33 @@ class HipKernels:
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
+        st = _stream(dev)
         y = torch.empty_like(x)
-        table = torch.empty((c, 8), dtype=torch.float32, device=dev)
-        gb = sl = bits = ws = None
+        # one small allocation: [table C*8 | gamma C | beta C | loss, acc] floats (+ bits as int8 when needed)
+        small = torch.empty(c * 10 + 2, dtype=torch.float32, device=dev)
+        base = small.data_ptr()
+        p_gamma, p_beta, p_loss = base + 32 * c, base + 36 * c, base + 40 * c
+        bits = None
         k = 0
         if weight is not None:
-            gb = torch.empty((2, c), dtype=torch.float32, device=dev)
             k = weight.numel() // c
         if b is not None:
-            sl = torch.empty(2, dtype=torch.float32, device=dev)
             bits = torch.empty(c, dtype=torch.int8, device=dev)
-        if training:
-            ws = torch.empty(lib.deepipr_passport_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        ws = self._scratch(dev, st, lib.deepipr_passport_bn_workspace_bytes(n, c, hw)) if training else None
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_fwd(
-                _p(x), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2, _p(running_mean),
-                _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu), _p(y), _p(table),
-                _p(gb[0]) if gb is not None else None, _p(gb[1]) if gb is not None else None,
-                _p(sl[0]) if sl is not None else None, _p(sl[1]) if sl is not None else None, _p(bits), _p(ws),
-                _stream(dev)), 'passport_bn_fwd')
-        return (y, table, gb[0] if gb is not None else None, gb[1] if gb is not None else None,
-                sl[0] if sl is not None else None, sl[1] if sl is not None else None, bits)
+                x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
+                _p(running_mean), _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu),
+                y.data_ptr(), base, p_gamma if weight is not None else None, p_beta if weight is not None else None,
+                p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), ws, st),
+                'passport_bn_fwd')
+        table = small[:8 * c].view(c, 8)
+        gamma = beta = loss = acc = None
+        if weight is not None:
+            gamma, beta = small[8 * c:9 * c], small[9 * c:10 * c]
+        if b is not None:
+            loss, acc = small[10 * c], small[10 * c + 1]
+        return y, table, gamma, beta, loss, acc, bits
 
     def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
                         margin=MARGIN, l2=L2):
@@ -229,18 +249,21 @@ class HipKernels:
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
-        ws = torch.empty(lib.deepipr_passport_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+        st = _stream(dev)
+        nws = lib.deepipr_passport_bn_workspace_bytes(n, c, hw)
+        nws = (nws + 255) // 256 * 256
+        scratch = self._scratch(dev, st, nws + 32 * c)          # partial sums | backward channel table
         dx = torch.empty_like(x)
         dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
-        table_out = torch.empty_like(table)
+        pg = dgb.data_ptr()
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_bwd(
-                _p(dy), _p(x), _p(table), _p(m), _p(b), alpha, margin, l2, _p(dloss), _p(dgamma_extra),
-                _p(dbeta_extra), int(training), n, c, hw, (dw.numel() // c) if dw is not None else 0, int(relu),
-                _p(dx), _p(dw), _p(dgb[0]), _p(dgb[1]), _p(table_out), _p(ws), _stream(dev)), 'passport_bn_bwd')
+                dy.data_ptr(), x.data_ptr(), table.data_ptr(), _p(m), _p(b), alpha, margin, l2, _p(dloss),
+                _p(dgamma_extra), _p(dbeta_extra), int(training), n, c, hw,
+                (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c,
+                scratch + nws, scratch, st), 'passport_bn_bwd')
         return dx, dw, dgb[0], dgb[1]
-
 
     def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
         """In-place SGD(momentum, weight decay) over flat fp32 buffers of equal length."""
