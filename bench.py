@@ -245,14 +245,15 @@ def main():
     timing = not args.no_kernel_timing
     D.barrier()
     torch.cuda.synchronize()
-    # in-situ kernel timing on every 4th step of the timed region (per-dispatch events cost ~0.1 ms of host
-    # time per step; sampling keeps that out of three quarters of the steps)
+    # in-situ kernel timing on every `stride`-th step of the timed region (dispatching with per-kernel events
+    # costs ~0.8 ms of host time on such a step; sampling keeps the timed region within ~1 % of an untimed one)
+    stride = max(1, min(10, args.steps // 3))
     if timing:
         _lib.profile_enable(1)
         _lib.profile_enable(0)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timing and i % 4 == 0:
+        if timing and i % stride == 0:
             _lib.profile_enable(2)
             step(i)
             _lib.profile_enable(0)
@@ -295,7 +296,7 @@ def main():
         # kernel execution time, comparable with rocprofv3's kernel trace.  The streaming kernels run once per
         # fused layer call (passport layers AND BatchNorm ConvBlocks), so bytes and time are summed over all
         # launches of the sampled steps: achieved = algorithmic bytes / kernel time.
-        sampled = len(range(0, args.steps, 4))
+        sampled = len(range(0, args.steps, stride))
         tot_elems = float(sum(all_elems))
         kern = {}
         for name, bpe in BYTES_PER_ELT.items():
