@@ -54,11 +54,17 @@ def build_model(args, device):
         np.random.seed(0)
         cls = AlexNetPassport if args.scheme == 1 else AlexNetPassportPrivate
         return cls(3, args.classes, kw, imagenet=getattr(args, 'image_size', 32) > 32).to(device)
-    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet18_passport.json')))
+    arch = getattr(args, 'arch', 'resnet18')
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', '%s_passport.json' % arch)))
     kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
                                               'sl_ratio': 0.1})
     torch.manual_seed(0)
     np.random.seed(0)
+    if arch == 'resnet50':                       # no reference implementation: see BottleneckPassportBlock
+        from deepipr_amd.models.resnet_passport import ResNet50Passport
+        assert args.scheme == 1, 'the ResNet50 passport variant exists for scheme V1 only'
+        return ResNet50Passport(num_classes=args.classes, passport_kwargs=kw,
+                                imagenet=getattr(args, 'image_size', 32) > 32).to(device)
     if args.scheme == 1:
         model = ResNet18Passport(num_classes=args.classes, passport_kwargs=kw, imagenet=getattr(args, 'image_size', 32) > 32)
     else:
@@ -110,6 +116,8 @@ def cpu_baseline(args, budget_s=20.0):
     torch.set_num_threads(threads)
     if arch == 'alexnet':
         model = torch_ref.AlexNetRef(3, args.classes, kw, private=args.scheme != 1)
+    elif arch == 'resnet50':
+        model = torch_ref.resnet50_ref(num_classes=args.classes, passport_kwargs=kw, imagenet=hw > 32)
     else:
         model = torch_ref.resnet18_ref(num_classes=args.classes, passport_kwargs=kw, private=args.scheme != 1,
                                        imagenet=hw > 32)
@@ -184,7 +192,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
     ap.add_argument('--scheme', type=int, default=1, choices=[1, 2])
     ap.add_argument('--classes', type=int, default=10)
-    ap.add_argument('--arch', default='resnet18', choices=['resnet18', 'alexnet'])
+    ap.add_argument('--arch', default='resnet18', choices=['resnet18', 'resnet50', 'alexnet'])
     ap.add_argument('--image-size', type=int, default=32, help='32 = CIFAR shapes, 224 = ImageNet shapes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -274,7 +282,7 @@ def main():
     fwd_per_step = 1 if args.scheme == 1 else 2
     out = {
         'metric': 'images/sec %s-passport %s train step' % (
-            'ResNet18' if args.arch == 'resnet18' else 'AlexNet',
+            {'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
             'CIFAR%d' % args.classes if args.image_size == 32 else 'ImageNet-shape'),
         'value': round(value, 1), 'unit': 'img/s',
         'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
@@ -282,7 +290,7 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s V%s passport (%s_passport.json: %d passport layers), '
                                '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
-                               ('ResNet18' if args.arch == 'resnet18' else 'AlexNet',
+                               ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
                                 '1' if args.scheme == 1 else '2 private', args.arch, len(elems), args.classes,
                                 args.image_size, args.image_size, args.batch),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,

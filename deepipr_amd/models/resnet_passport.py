@@ -124,3 +124,62 @@ def ResNet18Passport(**model_kwargs):
 
 def ResNet9Passport(**model_kwargs):
     return ResNetPassport(BasicPassportBlock, [1, 1, 1, 1], **model_kwargs)
+
+
+class BottleneckPassportBlock(nn.Module):
+    """Bottleneck (1x1 -> 3x3 -> 1x1, expansion 4) with per-conv passport flags, for BASELINE.json's ResNet50
+    configuration.  The reference has NO passport bottleneck (models/resnet_passport.py:183-188 only builds
+    BasicPassportBlock); this block is composed from its own pieces the way its plain Bottleneck
+    (models/resnet_normal.py:30-49) is: convbnrelu_1 / convbnrelu_2 with ReLU, convbn_3 and the projection
+    shortcut WITHOUT ReLU, ReLU after the residual add.  There is therefore no reference oracle for it; it is
+    pinned against the oracle's PassportLayerRef composed the same way (tests/test_parity_gpu.py)."""
+    expansion = 4
+    passport_cls = PassportBlock
+
+    def __init__(self, in_planes, planes, stride=1, passport_kwargs={}):
+        super().__init__()
+
+        def make(kw, i, o, ks, s, pd, relu):
+            if kw['flag']:
+                return self.passport_cls(i, o, ks, s, pd, passport_kwargs=kw, relu=relu)
+            from deepipr_amd.models.layers.conv2d import ConvBlock
+            return ConvBlock(i, o, ks, s, pd, bn=kw['norm_type'], relu=relu)
+        self.convbnrelu_1 = make(passport_kwargs['convbnrelu_1'], in_planes, planes, 1, 1, 0, True)
+        self.convbnrelu_2 = make(passport_kwargs['convbnrelu_2'], planes, planes, 3, stride, 1, True)
+        self.convbn_3 = make(passport_kwargs['convbn_3'], planes, self.expansion * planes, 1, 1, 0, False)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut = make(passport_kwargs['shortcut'], in_planes, self.expansion * planes, 1, stride, 0, False)
+
+    def has_projection(self):
+        return not isinstance(self.shortcut, nn.Sequential)
+
+    def set_intermediate_keys(self, pretrained_block, x, y=None):
+        def both(fn, a, b):
+            return fn(a), (fn(b) if b is not None else None)
+        out_x, out_y = x, y
+        for name in ('convbnrelu_1', 'convbnrelu_2', 'convbn_3'):
+            layer = getattr(self, name)
+            if isinstance(layer, PASSPORT_TYPES):
+                layer.set_key(out_x, out_y)
+            out_x, out_y = both(getattr(pretrained_block, name), out_x, out_y)
+        if self.has_projection():
+            if isinstance(self.shortcut, PASSPORT_TYPES):
+                self.shortcut.set_key(x, y)
+            sc_x, sc_y = both(pretrained_block.shortcut, x, y)
+        else:
+            sc_x, sc_y = x, y
+        return F.relu(out_x + sc_x), (F.relu(out_y + sc_y) if y is not None else None)
+
+    def forward(self, x, force_passport=False, ind=0):
+        out = run_layer(self.convbnrelu_1, x, force_passport, ind)
+        out = run_layer(self.convbnrelu_2, out, force_passport, ind)
+        out = run_layer(self.convbn_3, out, force_passport, ind)
+        sc = run_layer(self.shortcut, x, force_passport, ind) if self.has_projection() else x
+        return F.relu(out + sc)
+
+
+def ResNet50Passport(**model_kwargs):
+    """ResNet-50 (Bottleneck [3, 4, 6, 3]) with passport flags per conv: `passport_configs/resnet50_passport.json`
+    switches on layer4 (9 convs + the projection shortcut)."""
+    return ResNetPassport(BottleneckPassportBlock, [3, 4, 6, 3], **model_kwargs)

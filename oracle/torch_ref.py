@@ -171,12 +171,43 @@ class BasicBlockRef(nn.Module):
         return F.relu(out)
 
 
+class BottleneckRef(nn.Module):
+    """NOT in the reference: a passport Bottleneck composed from the reference's pieces the way its plain
+    Bottleneck is (models/resnet_normal.py:30-49): 1x1 -> 3x3 -> 1x1 (no ReLU) + projection (no ReLU), ReLU after
+    the add.  Checker for the build's BottleneckPassportBlock (BASELINE.json config 5 has no reference oracle)."""
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride, kw, private):
+        super().__init__()
+
+        def make(k, i, o, ks, s, pd, relu):
+            if k['flag']:
+                return PassportLayerRef(i, o, ks, s, pd, passport_kwargs=k, relu=relu, private=private)
+            return ConvBlockRef(i, o, ks, s, pd, bn=k['norm_type'], relu=relu)
+        self.convbnrelu_1 = make(kw['convbnrelu_1'], in_planes, planes, 1, 1, 0, True)
+        self.convbnrelu_2 = make(kw['convbnrelu_2'], planes, planes, 3, stride, 1, True)
+        self.convbn_3 = make(kw['convbn_3'], planes, 4 * planes, 1, 1, 0, False)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != 4 * planes:
+            self.shortcut = make(kw['shortcut'], in_planes, 4 * planes, 1, stride, 0, False)
+
+    def forward(self, x, force_passport=False, ind=0):
+        out = _call(self.convbnrelu_1, x, force_passport, ind)
+        out = _call(self.convbnrelu_2, out, force_passport, ind)
+        out = _call(self.convbn_3, out, force_passport, ind)
+        sc = x if isinstance(self.shortcut, nn.Sequential) else _call(self.shortcut, x, force_passport, ind)
+        return F.relu(out + sc)
+
+
 class ResNetRef(nn.Module):
     """ResNetPassport (models/resnet_passport.py:88-180) / ResNetPrivate
     (models/resnet_passport_private.py:89-182)."""
 
-    def __init__(self, num_blocks, num_classes=10, passport_kwargs={}, private=False, imagenet=False):
+    def __init__(self, num_blocks, num_classes=10, passport_kwargs={}, private=False, imagenet=False,
+                 block=None):
         super().__init__()
+        block = block or BasicBlockRef
+        exp = getattr(block, 'expansion', 1)
         self.in_planes = 64
         stem = _make_block(passport_kwargs['convbnrelu_1'], private)
         if num_classes == 1000 or imagenet:                                       # :94-98
@@ -187,10 +218,10 @@ class ResNetRef(nn.Module):
             name = 'layer%d' % (li + 1)
             blocks = []
             for bi, s in enumerate([stride] + [1] * (num_blocks[li] - 1)):         # :137-143
-                blocks.append(BasicBlockRef(self.in_planes, planes, s, passport_kwargs[name][str(bi)], private))
-                self.in_planes = planes
+                blocks.append(block(self.in_planes, planes, s, passport_kwargs[name][str(bi)], private))
+                self.in_planes = planes * exp
             setattr(self, name, nn.Sequential(*blocks))
-        self.linear = nn.Linear(512, num_classes)
+        self.linear = nn.Linear(512 * exp, num_classes)
 
     def forward(self, x, force_passport=False, ind=0):                           # :163-180
         if isinstance(self.convbnrelu_1, nn.Sequential):
@@ -210,6 +241,10 @@ def resnet18_ref(**kw):
 
 def resnet9_ref(**kw):
     return ResNetRef([1, 1, 1, 1], **kw)
+
+
+def resnet50_ref(**kw):
+    return ResNetRef([3, 4, 6, 3], block=BottleneckRef, **kw)
 
 
 # ----------------------------------------------------------------------------- AlexNet
