@@ -235,3 +235,32 @@ def test_resnet50_bottleneck_passport_matches_composed_oracle(cpu_kernels):
         # layer4 (the passport layers) and the classifier are the meaningful comparison
         tol = 1e-2 if name.startswith(('layer4', 'linear')) else 5e-2
         assert float((gp[name].grad - p.grad).abs().max()) <= tol * scale + 1e-7, name
+
+
+def test_flat_sgd_matches_torch_sgd_and_round_trips_state(cpu_kernels):
+    """FlatSGD on the host (oracle-backed SGD kernel): same trajectory as torch.optim.SGD, parameters live in one
+    flat buffer, lr schedulers act on it, state_dict carries the momentum."""
+    from deepipr_amd.flat_sgd import FlatSGD
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net_b = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net_b.load_state_dict(net_a.state_dict())
+    oa = torch.optim.SGD(net_a.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    ob = FlatSGD(net_b.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, [2], 0.1)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, [2], 0.1)
+    assert all(p.data_ptr() >= ob.flat_param.data_ptr() for p in net_b.parameters())
+    x = torch.randn(9, 7)
+    for i in range(4):
+        for net, opt, sch in ((net_a, oa, sa), (net_b, ob, sb)):
+            opt.zero_grad(set_to_none=True)
+            net(x).square().mean().backward()
+            opt.step()
+            sch.step()
+        if i == 1:                                                   # checkpoint the optimiser mid-run
+            saved = ob.state_dict()
+            ob.load_state_dict(saved)
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+    assert ob.param_groups[0]['lr'] == pytest.approx(0.01)
+    assert 'flat_momentum' in ob.state_dict()

@@ -642,6 +642,60 @@ def test_flat_sgd_equals_torch_sgd_on_gpu(K):
             assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
 
 
+def test_convblock_fused_norm_equals_library_ops():
+    """ConvBlock on the GPU: fused norm+affine+ReLU kernels (default above 1M elements) against MIOpen batch norm +
+    ATen ReLU on the same block: output, input/weight/bn gradients, running statistics; train and eval."""
+    from deepipr_amd.models.layers.conv2d import ConvBlock
+    torch.manual_seed(2)
+    a, b = ConvBlock(32, 64, 3, 1, 1).to(DEV), ConvBlock(32, 64, 3, 1, 1).to(DEV)
+    b.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        for blk in (a, b):
+            blk.bn.weight.copy_(1 + 0.3 * torch.randn(64, device=DEV, generator=torch.Generator(DEV).manual_seed(1)))
+            blk.bn.bias.copy_(0.2 * torch.randn(64, device=DEV, generator=torch.Generator(DEV).manual_seed(2)))
+    a.fuse_norm, b.fuse_norm = True, False
+    x = torch.randn(64, 32, 32, 32, device=DEV)                     # 4.2M output elements: fused path taken
+    cot = torch.randn(64, 64, 32, 32, device=DEV)
+    res = []
+    for blk in (a, b):
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        (y * cot).sum().backward()
+        res.append((y.detach(), xi.grad, blk.conv.weight.grad, blk.bn.weight.grad, blk.bn.bias.grad,
+                    blk.bn.running_mean.clone(), blk.bn.running_var.clone(), blk.bn.num_batches_tracked.clone()))
+    names = ('y', 'dx', 'dW', 'd bn.weight', 'd bn.bias', 'running_mean', 'running_var', 'num_batches_tracked')
+    for u, v, nm in zip(res[0], res[1], names):
+        u, v = u.float(), v.float()
+        assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 1e-6, nm
+    a.eval(), b.eval()
+    with torch.no_grad():
+        assert torch.allclose(a(x), b(x), rtol=1e-4, atol=1e-5)
+    small = torch.randn(2, 32, 8, 8, device=DEV)                    # below FUSE_MIN_ELEMENTS: library path either way
+    a.train(), b.train()
+    assert torch.allclose(a(small), b(small), rtol=1e-4, atol=1e-5)
+
+
+def test_in_situ_profile_counts_launches(K):
+    """deepipr_profile_enable / _read: per-dispatch events, counted per kernel, resumable."""
+    from deepipr_amd import _lib
+    x = torch.randn(8, 16, 8, 8, device=DEV)
+    g, b = torch.randn(16, device=DEV), torch.randn(16, device=DEV)
+    _lib.profile_enable(1)
+    for _ in range(3):
+        K.affine_relu_fwd(x, g, b, True)
+    _lib.profile_enable(0)
+    K.affine_relu_fwd(x, g, b, True)                                # not counted: paused
+    _lib.profile_enable(2)
+    K.affine_relu_bwd(x, x, g, b, True)
+    _lib.profile_enable(0)
+    prof = _lib.profile_read()
+    assert prof['affine_fwd'][1] == 3 and prof['affine_bwd'][1] == 1 and prof['reduce_partials'][1] == 1
+    assert 0.0 < prof['affine_fwd'][0] < 5.0                        # milliseconds for three tiny kernels
+    _lib.profile_enable(1)
+    _lib.profile_enable(0)
+    assert _lib.profile_read()['affine_fwd'] == (0.0, 0)
+
+
 def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
