@@ -264,3 +264,62 @@ def test_flat_sgd_matches_torch_sgd_and_round_trips_state(cpu_kernels):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
     assert ob.param_groups[0]['lr'] == pytest.approx(0.01)
     assert 'flat_momentum' in ob.state_dict()
+
+
+def test_sign_loss_module_api(cpu_kernels):
+    """SignLoss.add / get_loss (hinge only) / get_acc / set_b / reset / the 'scale_cache is None' errors
+    (models/losses/sign_loss.py:15-59)."""
+    from deepipr_amd.models.losses.sign_loss import SignLoss
+    from oracle import np_passport as npp
+    rs = np.random.RandomState(4)
+    g = torch.from_numpy((rs.standard_normal(48) * 0.2).astype(np.float32))
+    b = torch.from_numpy(np.where(rs.uniform(size=48) < 0.5, -1.0, 1.0).astype(np.float32))
+    sl = SignLoss(0.3, b.clone())
+    with pytest.raises(Exception, match='scale_cache is None'):
+        sl.get_loss()
+    with pytest.raises(Exception, match='scale_cache is None'):
+        sl.get_acc()
+    sl.add(g.view(1, -1, 1, 1))
+    sl.add(g.view(1, -1, 1, 1))                                       # accumulates (loss += ..., acc += ...)
+    loss64, acc64, _ = npp.sign_loss_fwd(g.numpy().astype(np.float64), b.numpy().astype(np.float64), 0.3)
+    assert float(sl.loss) == pytest.approx(2 * float(loss64), rel=1e-5)
+    assert float(sl.acc) == pytest.approx(2 * float(acc64), rel=1e-6)
+    hinge = (0.3 * np.maximum(-b.numpy() * g.numpy() + 0.1, 0)).sum()
+    assert float(sl.get_loss()) == pytest.approx(float(hinge), rel=1e-5)   # no L2 term here (sign_loss.py:25-30)
+    assert float(sl.get_acc()) == pytest.approx(float(acc64), rel=1e-6)
+    sl.set_b(-b)
+    assert float(sl.get_acc()) == pytest.approx(1.0 - float(acc64), abs=1e-6)
+    sl.reset()
+    assert sl.loss == 0 and sl.acc == 0 and sl.scale_cache is None
+    assert 'b' in sl.state_dict()
+
+
+def test_imagenet_geometries_and_mixed_flags(cpu_kernels):
+    """ImageNet-shaped stems/classifiers (alexnet_passport.py:29-30,65-82; resnet_passport.py:94-98), a passport
+    stem, and a block with convbnrelu_1 passported but convbn_2 plain (the reference's BasicPassportBlock
+    mis-dispatches that combination, resnet_passport.py:72; here it simply works)."""
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.alexnet_passport import AlexNetPassport
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    from deepipr_amd.models.resnet_passport import ResNet18Passport, ResNet9Passport
+    from oracle.cases import alexnet_config, resnet18_config
+    mk = lambda cfg: construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn',
+                                                          'key_type': 'random', 'sl_ratio': 0.1})
+    torch.manual_seed(0)
+    a = AlexNetPassport(3, 1000, mk(alexnet_config()))
+    assert a.features[0].conv.kernel_size == (11, 11) and len(a.classifier) == 7
+    a.eval()
+    assert tuple(a(torch.randn(1, 3, 224, 224)).shape) == (1, 1000)
+    cfg = resnet18_config()
+    cfg['convbnrelu_1'] = True                                       # passport stem
+    cfg['layer1']['0'] = {'convbnrelu_1': True, 'convbn_2': False}   # mixed block
+    r = ResNet18Passport(num_classes=10, passport_kwargs=mk(cfg), imagenet=True)
+    assert isinstance(r.convbnrelu_1[0], PassportBlock) and r.convbnrelu_1[0].conv.kernel_size == (7, 7)
+    r.train()
+    out = r(torch.randn(2, 3, 64, 64))
+    assert tuple(out.shape) == (2, 10)
+    sd = r.state_dict()
+    assert tuple(sd['convbnrelu_1.0.key'].shape) == (1, 3, 64, 64) and 'layer1.0.convbnrelu_1.skey' in sd
+    cfg9 = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet9_passport.json')))
+    r9 = ResNet9Passport(num_classes=10, passport_kwargs=mk(cfg9))
+    assert sum(isinstance(m, PassportBlock) for m in r9.modules()) == 3
