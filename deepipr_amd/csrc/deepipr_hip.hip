@@ -613,6 +613,22 @@ __global__ __launch_bounds__(kThreads) void k_affine_bwd_small(
             vxh = nxh;
         }
     }
+    if (pl.CT == 1) {     // one channel per workgroup: butterfly + four LDS words (see k_bn_walk_small)
+        double sgx = 0.0, sg = 0.0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sgx += static_cast<double>(a_gx[i]);
+            sg += static_cast<double>(a_g[i]);
+        }
+        double *red = reinterpret_cast<double *>(&sacc[0][0]);
+        sgx = block_sum(sgx, red);
+        sg = block_sum(sg, red + 4);
+        if (t == 0) {
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 0) * C + c0] = sgx;
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 1) * C + c0] = sg;
+        }
+        return;
+    }
     if (lane_on) {        // slots of channels beyond a partial tile are never read
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -936,6 +952,24 @@ __global__ __launch_bounds__(kThreads) void k_bn_walk_small(
             vdy = ndy;
             vx = nx;
         }
+    }
+    if (pl.CT == 1) {
+        // one channel per workgroup (planes of >= 64 floats): every thread holds partial sums of that channel,
+        // so a butterfly per wave + four LDS words finish it -- no staging of 1024 partials for one wave to re-read
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s0 += static_cast<double>(a0[i]);
+            s1 += static_cast<double>(a1[i]);
+        }
+        double *red = reinterpret_cast<double *>(&sacc[0][0]);
+        s0 = block_sum(s0, red);
+        s1 = block_sum(s1, red + 4);
+        if (t == 0) {
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 0) * C + c0] = s0;
+            part[(static_cast<size_t>(blockIdx.y) * 2 + 1) * C + c0] = s1;
+        }
+        return;
     }
     if (lane_on) {
 #pragma unroll
