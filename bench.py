@@ -275,6 +275,10 @@ def main():
         _lib.profile_enable(False)
     dt = D.max_over_ranks(dt, device)
 
+    # signature read-out after the run: sign(gamma) == b per passport layer (experiments/trainer_private.py:37-71)
+    from deepipr_amd.experiments.trainer_private import TesterPrivate
+    detect = TesterPrivate(model, device, verbose=False).test_signature()
+    model.train()
     if rank != 0:
         D.shutdown()
         return
@@ -288,6 +292,7 @@ def main():
         'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
         'config': {'workload': '%s V%s passport (%s_passport.json: %d passport layers), '
                                '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
