@@ -89,7 +89,6 @@ class OracleKernels:
     # ---- BatchNorm-fused entry points: stock ATen batch_norm on the host as the checker ----
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
                         momentum, eps, training, margin=npp.MARGIN, l2=npp.L2):
-        import torch.nn.functional as F
         x64 = x.detach().double()
         if training:
             mean = x64.mean(dim=(0, 2, 3))

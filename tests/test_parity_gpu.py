@@ -12,7 +12,7 @@ from oracle import np_passport as npp
 from oracle import patterns, runner, torch_ref
 from oracle.cases import ALPHA, CASES, SGD, resnet18_config
 from tests.compare import close, compare_case
-from tests.impls import OracleImpl, ProductImpl, load_golden
+from tests.impls import ProductImpl, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

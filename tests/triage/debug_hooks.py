@@ -50,7 +50,6 @@ for k in sorted(B, key=lambda s: (s.split('/')[1], s.split('/')[0])):
 
 # ---- which path is closer to float64 ground truth on the last passport layer? ----
 print('--- fp64 ground truth for layer4.1.convbn_2 (public branch) ---')
-from deepipr_amd import passport_ops as PO
 
 
 def layer_truth(fuse):

@@ -1,12 +1,10 @@
 #!/usr/bin/env python
 """Experiments on how to drive the whole train step (not part of the product): eager vs hipGraph capture,
 MIOpen find mode on/off, channels_last.  Prints ms/step per variant."""
-import json
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -41,7 +41,7 @@ from models.layers.passportconv2d_private import PassportPrivateBlock  # noqa: E
 from models.resnet_passport import ResNet18Passport                  # noqa: E402
 from models.resnet_passport_private import ResNet18Private           # noqa: E402
 
-from oracle import patterns, runner                                  # noqa: E402
+from oracle import runner                                            # noqa: E402
 from oracle.cases import ALPHA, CASES                                # noqa: E402
 
 

@@ -5,9 +5,8 @@ Each kernel is launched `reps` times back to back between two HIP events (so the
 ~1.5 us kernel boundary); run the script under `rocprofv3 --kernel-trace --stats` for pure kernel
 durations.  Prints one line per (kernel, shape): us per launch and algorithmic GB/s.
 """
-import sys
 import os
-import json
+import sys
 
 import torch
 
