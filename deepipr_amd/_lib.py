@@ -43,6 +43,8 @@ SIGNATURES = {
     'deepipr_passport_bwd_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p,
                                     _f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp, _vp]),
+    'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
+    'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
@@ -97,7 +99,7 @@ def check(rc, what):
 
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
-                   'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd']
+                   'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu']
 
 
 def profile_enable(on):

@@ -3,6 +3,7 @@ intermediate passports (reference models/resnet_normal.py:9-143).  Library ops o
 import torch.nn as nn
 import torch.nn.functional as F
 
+from deepipr_amd import passport_ops as P
 from deepipr_amd.models.layers.conv2d import ConvBlock
 
 
@@ -18,7 +19,7 @@ class BasicBlock(nn.Module):
             self.shortcut = ConvBlock(in_planes, self.expansion * planes, 1, stride, 0, bn=norm_type, relu=True)
 
     def forward(self, x):
-        return F.relu(self.convbn_2(self.convbnrelu_1(x)) + self.shortcut(x))
+        return P.add_relu(self.convbn_2(self.convbnrelu_1(x)), self.shortcut(x))
 
 
 class Bottleneck(nn.Module):
@@ -35,7 +36,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = self.convbn_3(self.convbnrelu_2(self.convbnrelu_1(x)))
-        return F.relu(out + self.shortcut(x))
+        return P.add_relu(out, self.shortcut(x))
 
 
 class ResNet(nn.Module):

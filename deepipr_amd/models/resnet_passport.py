@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from deepipr_amd import passport_ops as P
 from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 
@@ -58,11 +59,8 @@ class BasicPassportBlock(nn.Module):
     def forward(self, x, force_passport=False, ind=0):
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
         out = run_layer(self.convbn_2, out, force_passport, ind)
-        if self.has_projection():
-            out = out + run_layer(self.shortcut, x, force_passport, ind)
-        else:
-            out = out + x
-        return F.relu(out)
+        sc = run_layer(self.shortcut, x, force_passport, ind) if self.has_projection() else x
+        return P.add_relu(out, sc)                       # out + shortcut, ReLU: one fused pass on the GPU
 
 
 class ResNetPassport(nn.Module):
@@ -176,7 +174,7 @@ class BottleneckPassportBlock(nn.Module):
         out = run_layer(self.convbnrelu_2, out, force_passport, ind)
         out = run_layer(self.convbn_3, out, force_passport, ind)
         sc = run_layer(self.shortcut, x, force_passport, ind) if self.has_projection() else x
-        return F.relu(out + sc)
+        return P.add_relu(out, sc)
 
 
 def ResNet50Passport(**model_kwargs):

@@ -265,6 +265,22 @@ class HipKernels:
                 scratch + nws, scratch, st), 'passport_bn_bwd')
         return dx, dw, dgb[0], dgb[1]
 
+    def add_relu_fwd(self, a, b):
+        dev = _chk(a, b)
+        out = torch.empty_like(a)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_add_relu_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
+                                                      _stream(dev)), 'add_relu_fwd')
+        return out
+
+    def relu_bwd(self, dy, out):
+        dev = _chk(dy, out)
+        dx = torch.empty_like(out)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_relu_bwd(dy.data_ptr(), out.data_ptr(), dx.data_ptr(), out.numel(),
+                                                  _stream(dev)), 'relu_bwd')
+        return dx
+
     def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
         """In-place SGD(momentum, weight decay) over flat fp32 buffers of equal length."""
         dev = _chk(flat_param, flat_grad, flat_buf)
@@ -491,6 +507,36 @@ def _bn_uses_batch_stats(bn):
 def bn_is_fusable(bn):
     """nn.BatchNorm2d without affine parameters and with the default exponential running average."""
     return (isinstance(bn, torch.nn.BatchNorm2d) and not bn.affine and bn.momentum is not None)
+
+
+class _AddReLU(torch.autograd.Function):
+    """out = relu(a + b), the residual tail of a block, in one pass; the backward mask is read from `out`."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = kernels.add_relu_fwd(a.contiguous(), b.contiguous())
+        ctx.save_for_backward(out)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None
+        (out,) = ctx.saved_tensors
+        d = kernels.relu_bwd(dy.contiguous(), out)
+        return d, d
+
+
+def add_relu(a, b):
+    """relu(a + b) through the fused kernel for same-shape fp32 GPU tensors, the library ops otherwise."""
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
+            and a.numel() >= ADD_RELU_MIN_ELEMENTS):
+        return _AddReLU.apply(a, b)
+    return torch.relu(a + b)
+
+
+ADD_RELU_MIN_ELEMENTS = 1 << 18
 
 
 def affine_relu(xhat, gamma, beta, relu=True):

@@ -56,7 +56,8 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_BN_BWD_REDUCE 13
 #define DEEPIPR_K_BN_AFFINE_BWD 14
 #define DEEPIPR_K_SGD 15
-#define DEEPIPR_PROFILE_KERNELS 16
+#define DEEPIPR_K_ADD_RELU 16
+#define DEEPIPR_PROFILE_KERNELS 17
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 
@@ -188,6 +189,13 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
  *           weight_decay=1e-4) from experiments/classification.py:47-50. */
 int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
                               float momentum, float weight_decay, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------ residual tail of a block
+ * out = relu(a + b) in one pass (12 B/element), and its backward d = dy * [out > 0] (the same gradient goes
+ * to both inputs).  All pointers 16-byte aligned, n floats.
+ * replaces: `out = out + shortcut; out = F.relu(out)`, models/resnet_passport.py:77-84 (private twin :79-86). */
+int deepipr_add_relu_fwd(const float *a, const float *b, float *out, size_t n, void *stream);
+int deepipr_relu_bwd(const float *dy, const float *out, float *dx, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -696,6 +696,25 @@ def test_in_situ_profile_counts_launches(K):
     assert _lib.profile_read()['affine_fwd'] == (0.0, 0)
 
 
+@pytest.mark.parametrize('shape', [(128, 512, 4, 4), (64, 64, 32, 32), (3, 5, 7, 9), (1, 1, 1, 263)])
+def test_add_relu_fused_tail(K, shape):
+    """out = relu(a + b) and d = dy * [out > 0]: bit-exact against the ATen ops they replace."""
+    rs = np.random.RandomState(sum(shape))
+    a, b, dy = [dev(rs.standard_normal(shape)) for _ in range(3)]
+    out = K.add_relu_fwd(a, b)
+    assert torch.equal(out, torch.relu(a + b))
+    d = K.relu_bwd(dy, out)
+    assert torch.equal(d, torch.where(out > 0, dy, torch.zeros_like(dy)))
+    from deepipr_amd import passport_ops as P
+    big = shape if a.numel() >= P.ADD_RELU_MIN_ELEMENTS else None
+    if big:
+        a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (P.add_relu(a1, b1) * dy).sum().backward()
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (torch.relu(a2 + b2) * dy).sum().backward()
+        assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+
+
 def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
