@@ -37,7 +37,13 @@ def _chk(*tensors):
     return dev
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(dev):
+    """hipStream_t of torch's current stream on `dev` (raw handle; no Stream object is built on the hot path)."""
+    if _raw_stream is not None and dev.index is not None:
+        return _raw_stream(dev.index)
     return torch.cuda.current_stream(dev).cuda_stream
 
 
@@ -198,6 +204,15 @@ class HipKernels:
     # round-trips per layer call on the host.
     _arena = {}
 
+    _ws_bytes = {}
+
+    def _bn_ws_bytes(self, n, c, hw):
+        key = (n, c, hw)
+        v = self._ws_bytes.get(key)
+        if v is None:
+            v = self._ws_bytes[key] = _lib.lib().deepipr_passport_bn_workspace_bytes(n, c, hw)
+        return v
+
     def _scratch(self, dev, stream, nbytes):
         key = (dev.index, stream)
         buf = self._arena.get(key)
@@ -210,7 +225,7 @@ class HipKernels:
                         momentum, eps, training, margin=MARGIN, l2=L2):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x.
         -> y, table[C,8], gamma, beta, loss, acc, bits  (gamma/beta None on the W-less public branch)."""
-        dev = _chk(x, weight, m, gamma_in, beta_in, b, running_mean, running_var)
+        dev = _chk(x, weight)                     # the small per-channel vectors come from this module's own code
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
@@ -226,7 +241,7 @@ class HipKernels:
             k = weight.numel() // c
         if b is not None:
             bits = torch.empty(c, dtype=torch.int8, device=dev)
-        ws = self._scratch(dev, st, lib.deepipr_passport_bn_workspace_bytes(n, c, hw)) if training else None
+        ws = self._scratch(dev, st, self._bn_ws_bytes(n, c, hw)) if training else None
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_fwd(
                 x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
@@ -245,13 +260,12 @@ class HipKernels:
     def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
                         margin=MARGIN, l2=L2):
         """-> dx, dW (None when wshape is None), dgamma, dbeta."""
-        dev = _chk(dy, x, table, m, b, dloss, dgamma_extra, dbeta_extra)
+        dev = _chk(dy, x)
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
         st = _stream(dev)
-        nws = lib.deepipr_passport_bn_workspace_bytes(n, c, hw)
-        nws = (nws + 255) // 256 * 256
+        nws = (self._bn_ws_bytes(n, c, hw) + 255) // 256 * 256
         scratch = self._scratch(dev, st, nws + 32 * c)          # partial sums | backward channel table
         dx = torch.empty_like(x)
         dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
