@@ -1,0 +1,1 @@
+"""Model families of the passport hot path (host mirror of the reference's `models` package)."""

@@ -1,0 +1,1 @@
+"""Conv blocks: plain ConvBlock and the V1 / private passport layers."""

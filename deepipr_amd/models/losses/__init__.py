@@ -1,0 +1,1 @@
+"""Hinge sign loss on the passport scale (gamma)."""

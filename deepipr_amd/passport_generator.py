@@ -1,37 +1,54 @@
-"""Passport image sampling and key installation (reference passport_generator.py:6-43).
+"""Passport sampling and key installation (the one-time set-up behind `--key-type image|shuffle`).
 
-One-time setup, not on the per-step path: n images are drawn from a loader's dataset and pushed through a
-(pre-trained) plain network; every passport layer receives the activations that feed it
-(`set_intermediate_keys`), reduced to one [1,C,H,W] passport by `passport_selection`."""
+Behavioural twin of the reference's passport_generator.py:6-43, organised around one small class:
+a `PassportSampler` draws candidate images from a loader's dataset with python's `random` (so seeded runs pick
+the same images as the reference) and `install()` pushes them through a plain "key propagation" network while
+every passport layer of the target network records the activations that feed it (`set_intermediate_keys`,
+which reduces 20 candidates to one passport per layer through `passport_selection`).
+"""
 import random
 
 import torch
 
 
+class PassportSampler:
+    def __init__(self, dataset_loader):
+        self.dataset = dataset_loader.dataset
+
+    def draw(self, n):
+        """n distinct samples -> (stacked images [n,C,H,W], their dataset indices)."""
+        picked = random.sample(range(len(self.dataset)), n)
+        images = torch.stack([self.dataset[idx][0] for idx in picked], dim=0)
+        return images, picked
+
+    @staticmethod
+    def install(key_net, target_net, bias_keys, scale_keys=None, ind=None):
+        """bias_keys feed `key` (beta), scale_keys feed `skey` (gamma) of every passport layer of target_net."""
+        bias_keys = _as_batch(bias_keys)
+        scale_keys = None if scale_keys is None else _as_batch(scale_keys)
+        extra = () if ind is None else (ind,)
+        target_net.set_intermediate_keys(key_net, bias_keys, scale_keys, *extra)
+
+
+def _as_batch(t):
+    return t.unsqueeze(0) if t.dim() == 3 else t
+
+
+# ---- the reference's function-style entry points ---------------------------------------------------------
 def get_key(dataset_loader, n=32):
-    """n distinct random samples of the loader's dataset, stacked -> ([n,C,H,W], indices)."""
-    dataset = dataset_loader.dataset
-    indices = random.sample(range(len(dataset)), n)
-    return torch.cat([dataset[i][0].unsqueeze(0) for i in indices], dim=0), indices
-
-
-def get_intermediate_key(input_key, intermediate_key_name, pretrained_model):
-    """Activation entering `features.<i>` of a plain AlexNet (passport_generator.py:20-27)."""
-    x = input_key
-    with torch.no_grad():
-        for i, m in enumerate(pretrained_model.features):
-            if 'features.%d' % i == intermediate_key_name:
-                return x
-            x = m(x)
+    return PassportSampler(dataset_loader).draw(n)
 
 
 def set_key(pretrained_model, target_model, key_x, key_y, ind=None):
-    """key_x -> bias keys, key_y -> scale keys of every passport layer of target_model."""
-    if key_x.dim() == 3:
-        key_x = key_x.unsqueeze(0)
-    if key_y is not None and key_y.dim() == 3:
-        key_y = key_y.unsqueeze(0)
-    if ind is not None:
-        target_model.set_intermediate_keys(pretrained_model, key_x, key_y, ind)
-    else:
-        target_model.set_intermediate_keys(pretrained_model, key_x, key_y)
+    PassportSampler.install(pretrained_model, target_model, key_x, key_y, ind)
+
+
+def get_intermediate_key(input_key, intermediate_key_name, pretrained_model):
+    """Activation that enters `features.<i>` of a plain AlexNet-style net, or None if no layer has that name."""
+    act = input_key
+    with torch.no_grad():
+        for idx, layer in enumerate(pretrained_model.features):
+            if intermediate_key_name == 'features.%d' % idx:
+                return act
+            act = layer(act)
+    return None
