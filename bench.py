@@ -242,10 +242,11 @@ def main():
 
     all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
     if args.graph:
-        assert world == 1, '--graph is single-GPU only'
+        assert not args.ddp, '--graph works with FlatSGD, not with DistributedDataParallel hooks'
         from deepipr_amd.experiments.graph_step import GraphedTrainStep
         fn = train_step_v1 if args.scheme == 1 else train_step_v23
-        graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0])
+        import torch.distributed as tdist
+        graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
         step = lambda i: graphed(xs[i % nb], ys[i % nb])
         args.no_kernel_timing = True                       # per-dispatch events cannot be captured
     for i in range(args.warmup):

@@ -12,12 +12,33 @@ key means are cached outside the graph); in-situ kernel timing (deepipr_profile_
 import torch
 
 
-class GraphedTrainStep:
-    """step_fn(model, optimizer, data, target) -> tuple of device scalars, captured once and replayed."""
+class _NoStep:
+    """Optimizer proxy handed to step_fn while capturing in 'fwd_bwd' mode: zero_grad is recorded, step() is not."""
 
-    def __init__(self, step_fn, model, optimizer, data, target, warmup=3):
+    def __init__(self, optimizer):
+        self._opt = optimizer
+
+    def zero_grad(self, *a, **k):
+        return self._opt.zero_grad(*a, **k)
+
+    def step(self, *a, **k):
+        return None
+
+
+class GraphedTrainStep:
+    """step_fn(model, optimizer, data, target) -> tuple of device scalars, captured once and replayed.
+
+    optimizer_in_graph=True  (single GPU): the whole step, optimiser included, is one hipGraph.
+    optimizer_in_graph=False (data parallel): zero_grad -> forward -> losses -> backward are captured; after each
+        replay optimizer.step() runs eagerly -- with FlatSGD that is: pack the (static-address) gradients bucket by
+        bucket, all-reduce them over RCCL, one fused SGD kernel.  No collective is ever captured, so the graph
+        contains only this process's own kernels."""
+
+    def __init__(self, step_fn, model, optimizer, data, target, warmup=3, optimizer_in_graph=True):
         self.static_data = data.clone()
         self.static_target = target.clone()
+        self.optimizer = optimizer
+        self.optimizer_in_graph = optimizer_in_graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up off the capture stream: MIOpen find,
@@ -30,8 +51,17 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = step_fn(model, optimizer, self.static_data, self.static_target)
+        captured_opt = optimizer if optimizer_in_graph else _NoStep(optimizer)
+        hooks_off = getattr(optimizer, 'pause_hooks', None)
+        # with a process group alive, RCCL's watchdog thread polls events concurrently: only this thread's calls
+        # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
+        mode = 'global' if optimizer_in_graph else 'thread_local'
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            if hooks_off is not None and not optimizer_in_graph:
+                with hooks_off():                          # no collective may be launched while capturing
+                    self.outputs = step_fn(model, captured_opt, self.static_data, self.static_target)
+            else:
+                self.outputs = step_fn(model, captured_opt, self.static_data, self.static_target)
 
     def _dry_run(self, step_fn, model, optimizer):
         base = model
@@ -62,4 +92,6 @@ class GraphedTrainStep:
         self.static_data.copy_(data, non_blocking=True)
         self.static_target.copy_(target, non_blocking=True)
         self.graph.replay()
+        if not self.optimizer_in_graph:
+            self.optimizer.step()
         return self.outputs

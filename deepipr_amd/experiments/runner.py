@@ -159,7 +159,7 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
         opt = FlatSGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001)
         wrap = lambda m: m
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
-    graph = bool(args.get('graph')) and world == 1
+    graph = bool(args.get('graph')) and not args.get('ddp')      # DDP's own hooks cannot be captured
     if private:
         net = wrap(DualBranch(model))
         trainer = TrainerPrivate(net, opt, sched, device, graph=graph)

@@ -108,6 +108,8 @@ class StepRunner:
     def __init__(self, step_fn, model, optimizer, graph=False):
         self.step_fn, self.model, self.optimizer = step_fn, model, optimizer
         self.graph = graph
+        # data parallel: capture forward+backward only, exchange gradients and step eagerly after each replay
+        self.opt_in_graph = not (torch.distributed.is_available() and torch.distributed.is_initialized())
         self._graphed = None
         self._shape = None
 
@@ -116,7 +118,8 @@ class StepRunner:
             return self.step_fn(self.model, self.optimizer, data, target)
         if self._graphed is None:
             from deepipr_amd.experiments.graph_step import GraphedTrainStep
-            self._graphed = GraphedTrainStep(self.step_fn, self.model, self.optimizer, data, target, warmup=0)
+            self._graphed = GraphedTrainStep(self.step_fn, self.model, self.optimizer, data, target, warmup=0,
+                                             optimizer_in_graph=self.opt_in_graph)
             self._shape = (tuple(data.shape), tuple(target.shape))
             return self._graphed(data, target)          # capture does not execute: replay the first batch
         if (tuple(data.shape), tuple(target.shape)) != self._shape:

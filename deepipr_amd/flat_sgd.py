@@ -83,6 +83,7 @@ class FlatSGD(torch.optim.Optimizer):
         self._launched = [False] * len(self._buckets)
         self._works = []
         self._hooks = []
+        self._paused = False
         if self.comm and len(self._buckets) > 1:
             for p, _ in self._slots[:self._buckets[-1][0]]:          # every bucket but the last
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -126,7 +127,24 @@ class FlatSGD(torch.optim.Optimizer):
             if async_op:
                 self._works.append(w)
 
+    def pause_hooks(self):
+        """Context manager: gradient hooks do nothing inside (used while a hipGraph of forward+backward is being
+        captured -- the exchange then happens in step(), after the replay)."""
+        opt = self
+
+        class _Pause:
+            def __enter__(self):
+                opt._paused = True
+
+            def __exit__(self, *exc):
+                opt._paused = False
+                opt._pending = [hi - lo for lo, hi in opt._buckets]
+                return False
+        return _Pause()
+
     def _on_grad(self, param):
+        if self._paused:
+            return
         b = self._bucket_of[id(param)]
         self._pending[b] -= 1
         if self._pending[b] == 0 and not self._launched[b]:

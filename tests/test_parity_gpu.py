@@ -715,6 +715,42 @@ def test_add_relu_fused_tail(K, shape):
         assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
 
 
+def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
+    """Data-parallel form of the graphed step: forward+backward replayed from a hipGraph, FlatSGD's bucketed
+    exchange (forced on in a one-rank nccl group) and the fused SGD kernel run eagerly after each replay.  Must
+    equal the plain eager trajectory."""
+    import torch.distributed as dist
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.flat_sgd import FlatSGD
+    monkeypatch.setenv('DEEPIPR_FORCE_DDP', '1')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1)
+    bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    try:
+        finals = []
+        for graphed in (False, True):
+            prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+            x, y = x.to(DEV), y.to(DEV)
+            opt = FlatSGD(prod.parameters(), **SGD)
+            assert opt.comm and len(opt._buckets) >= 3
+            if graphed:
+                g = GraphedTrainStep(train_step_v1, prod, opt, x, y, warmup=0, optimizer_in_graph=False)
+                for i in range(3):
+                    g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+            else:
+                for i in range(3):
+                    train_step_v1(prod, opt, x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+            torch.cuda.synchronize()
+            finals.append({k: v.clone() for k, v in prod.state_dict().items()})
+        for k in finals[0]:
+            if finals[0][k].dtype.is_floating_point:
+                assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+        dist.destroy_process_group()
+
+
 def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
