@@ -189,14 +189,11 @@ __global__ __launch_bounds__(kThreads) void k_pooled_patch_mean(
 // 16 B/lane loads, the two pooled f64 vectors come from L2 and are reused for the RPW rows (they are
 // 4x the bytes of a row, so RPW=2 halves the L2->CU traffic); f64 FMA accumulation.
 // ============================================================================================
+// as[r], ab[r] = this thread's partial dot products of rows co0..co0+RPW-1 with the two pooled vectors.
 template <bool VEC, int RPW>
-__global__ __launch_bounds__(kThreads) void k_gamma_beta(
-    const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
-    float *__restrict__ gamma, float *__restrict__ beta) {
-    __shared__ double red[8 * RPW];
-    const int co0 = blockIdx.x * RPW;
+__device__ __forceinline__ void gemv_rows(const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
+                                          int co0, double (&as)[RPW], double (&ab)[RPW]) {
     const double *ss = s, *sb = s + K;
-    double as[RPW], ab[RPW];
     const float *row[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -236,6 +233,16 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta(
             }
         }
     }
+}
+
+template <bool VEC, int RPW>
+__global__ __launch_bounds__(kThreads) void k_gamma_beta(
+    const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
+    float *__restrict__ gamma, float *__restrict__ beta) {
+    __shared__ double red[8 * RPW];
+    const int co0 = blockIdx.x * RPW;
+    double as[RPW], ab[RPW];
+    gemv_rows<VEC, RPW>(W, s, Co, K, co0, as, ab);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         as[r] = block_sum(as[r], red + 8 * r);
@@ -817,47 +824,8 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta_bn(
     float *__restrict__ gamma, float *__restrict__ beta, BnFinishArgs f) {
     __shared__ double red[8 * RPW];
     const int co0 = blockIdx.x * RPW;
-    const double *ss = s, *sb = s + K;
     double as[RPW], ab[RPW];
-    const float *row[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        as[r] = 0.0;
-        ab[r] = 0.0;
-        row[r] = W + static_cast<size_t>(min(co0 + r, Co - 1)) * K;
-    }
-    if (VEC) {
-        const double2 *ss2 = reinterpret_cast<const double2 *>(ss);
-        const double2 *sb2 = reinterpret_cast<const double2 *>(sb);
-        for (int q = threadIdx.x; q < K / 4; q += kThreads) {
-            float4 w[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) w[r] = reinterpret_cast<const float4 *>(row[r])[q];
-            const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
-            const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                as[r] = fma(static_cast<double>(w[r].x), s0.x, as[r]);
-                as[r] = fma(static_cast<double>(w[r].y), s0.y, as[r]);
-                as[r] = fma(static_cast<double>(w[r].z), s1.x, as[r]);
-                as[r] = fma(static_cast<double>(w[r].w), s1.y, as[r]);
-                ab[r] = fma(static_cast<double>(w[r].x), b0.x, ab[r]);
-                ab[r] = fma(static_cast<double>(w[r].y), b0.y, ab[r]);
-                ab[r] = fma(static_cast<double>(w[r].z), b1.x, ab[r]);
-                ab[r] = fma(static_cast<double>(w[r].w), b1.y, ab[r]);
-            }
-        }
-    } else {
-        for (int k = threadIdx.x; k < K; k += kThreads) {
-            const double vs = ss[k], vb = sb[k];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const double w = static_cast<double>(row[r][k]);
-                as[r] = fma(w, vs, as[r]);
-                ab[r] = fma(w, vb, ab[r]);
-            }
-        }
-    }
+    gemv_rows<VEC, RPW>(W, s, Co, K, co0, as, ab);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         as[r] = block_sum(as[r], red + 8 * r);
