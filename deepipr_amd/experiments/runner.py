@@ -68,6 +68,17 @@ def scheme_of(args, private):
     return 3 if args['train_backdoor'] else 2
 
 
+def next_experiment_id(root):
+    """Smallest positive integer not yet used as a sub-directory name of `root` (experiments/base.py:76-83)."""
+    used = set()
+    if os.path.isdir(root):
+        used = {int(d) for d in os.listdir(root) if d.isdigit() and os.path.isdir(os.path.join(root, d))}
+    i = 1
+    while i in used:
+        i += 1
+    return i
+
+
 def build_model(args, private, num_classes, device):
     cfg = json.load(open(args['passport_config']))
     kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': args['norm_type'],
@@ -168,20 +179,35 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
         trainer = Trainer(net, opt, sched, device, graph=graph)
 
     scheme = scheme_of(args, private)
-    logdir = os.path.join(args.get('logdir') or 'logs', '%s_%s_v%d%s' % (
-        args['arch'], dataset, scheme, '_' + args['tag'] if args.get('tag') else ''), str(args['exp_id']))
+    # logs/<arch>_<dataset>_v<scheme>[_tag]/<id>/{config.json, history.csv, models/{best,last,epoch-N}.pth}
+    # (experiments/base.py:57-74,110-150): training takes the smallest unused id, --eval reads --exp-id's best.pth
+    root = os.path.join(args.get('logdir') or 'logs', '%s_%s_v%d%s' % (
+        args['arch'], dataset, scheme, '_' + args['tag'] if args.get('tag') else ''))
+    if args.get('eval'):
+        logdir = os.path.join(root, str(args['exp_id']))
+        path = os.path.join(logdir, 'models', 'best.pth')
+        if os.path.exists(path):
+            model.load_state_dict(torch.load(path, map_location='cpu'))
+        else:
+            print('Warning: No such Experiment -> %s' % path)
+        return trainer.test(valid_loader)
+    exp_id = [next_experiment_id(root) if rank == 0 else 0]
+    if world > 1:
+        torch.distributed.broadcast_object_list(exp_id, src=0)
+    logdir = os.path.join(root, str(exp_id[0]))
     history = []
+    best_acc = float('-inf')
     if rank == 0:
         os.makedirs(os.path.join(logdir, 'models'), exist_ok=True)
-        json.dump({k: v for k, v in args.items()}, open(os.path.join(logdir, 'config.json'), 'w'), indent=2)
-    if args.get('eval'):
-        return trainer.test(valid_loader)
+        json.dump({k: v for k, v in args.items()}, open(os.path.join(logdir, 'config.json'), 'w'), indent=4)
     for ep in range(1, epochs + 1):
         t0 = time.time()
         row = {'epoch': ep}
         row.update({'train_' + k: v for k, v in trainer.train(ep, train_loader, wm_loader).items()})
         if rank == 0:
             row.update({'valid_' + k: v for k, v in trainer.test(valid_loader).items()})
+            if wm_loader is not None:
+                row.update({'wm_' + k: v for k, v in trainer.test(wm_loader, 'WM Result').items()})
             n_img = len(train_loader) * per_gpu * world
             row['train_img_per_s'] = n_img / max(1e-9, row['train_time'])
             history.append(row)
@@ -191,6 +217,11 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
                 w.writeheader()
                 w.writerows(history)
             sd = {k: v.cpu() for k, v in model.state_dict().items()}
+            # best.pth follows valid_acc (classification.py:298-301) / valid_total_acc (classification_private.py:150-153)
+            score = row.get('valid_total_acc' if private else 'valid_acc', float('-inf'))
+            if score > best_acc:
+                best_acc = score
+                torch.save(sd, os.path.join(logdir, 'models', 'best.pth'))
             torch.save(sd, os.path.join(logdir, 'models', 'last.pth'))
             if args['save_interval'] and ep % args['save_interval'] == 0:
                 torch.save(sd, os.path.join(logdir, 'models', 'epoch-%d.pth' % ep))

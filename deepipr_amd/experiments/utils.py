@@ -35,3 +35,78 @@ def construct_passport_kwargs(self, need_index=False):
 def construct_passport_kwargs_from_dict(self, need_index=False):
     """Same, from a plain dict with those four keys."""
     return _build(self['passport_config'], self['norm_type'], self['key_type'], self['sl_ratio'], need_index)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Weight shuttles between plain and passport nets (reference experiments/utils.py:100-239), used by the transfer
+# learning / attack scripts.  A passport layer's (gamma, beta) play the role of the plain layer's affine norm
+# weights, so moving a net across means: copy every feature stage's tensors that have a namesake on the other
+# side (non-strict), then carry gamma/beta <-> bn.weight/bn.bias for the layers named in `plkeys`
+# (AlexNet: '4'; ResNet: 'layer4.0.convbnrelu_1'), and -- AlexNet only -- the hidden classifier layers, never
+# the last one (the class count may differ).
+# ---------------------------------------------------------------------------------------------------------------
+_RESNET_STAGES = ('convbnrelu_1', 'layer1', 'layer2', 'layer3', 'layer4')
+
+
+def _stages(arch):
+    return ('features',) if arch == 'alexnet' else _RESNET_STAGES
+
+
+def _block(model, arch, plkey):
+    if arch == 'alexnet':
+        return model.features[int(plkey)]
+    stage, index, name = plkey.split('.')
+    return getattr(getattr(model, stage)[int(index)], name)
+
+
+def _copy_stages(arch, src, dst, strict):
+    for name in _stages(arch):
+        getattr(dst, name).load_state_dict(getattr(src, name).state_dict(), strict=strict)
+
+
+def _copy_hidden_classifier(src, dst):
+    import torch.nn as nn
+    if not isinstance(dst.classifier, nn.Sequential):
+        return
+    layers = list(zip(src.classifier, dst.classifier))
+    for s, d in layers[:-1]:
+        d.load_state_dict(s.state_dict())
+
+
+def load_normal_model_to_passport_model(arch, plkeys, passport_model, model):
+    """plain `model` -> `passport_model`: V1 passport layers get learnable scale/bias Parameters (so that the
+    copied norm weights are what get_scale()/get_bias() return), private layers use their public pair."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    for m in passport_model.modules():
+        if isinstance(m, PassportBlock):
+            m.init_scale(True)
+            m.init_bias(True)
+    _copy_stages(arch, model, passport_model, strict=False)
+    for k in plkeys:
+        src, dst = _block(model, arch, k), _block(passport_model, arch, k)
+        dst.scale.data.copy_(src.bn.weight.data)
+        dst.bias.data.copy_(src.bn.bias.data)
+    if arch == 'alexnet':
+        _copy_hidden_classifier(model, passport_model)
+
+
+def load_normal_model_to_normal_model(arch, new_model, model):
+    """plain `model` -> plain `new_model` (AlexNet strictly; ResNet stage by stage, names that match)."""
+    _copy_stages(arch, model, new_model, strict=(arch == 'alexnet'))
+    if arch == 'alexnet':
+        _copy_hidden_classifier(model, new_model)
+
+
+def load_passport_model_to_normal_model(arch, plkeys, passport_model, model):
+    """`passport_model` -> plain `model`: the passport layers' current gamma/beta (learnable pair if present,
+    else derived from the keys -- a GEMV on the device) become the plain layers' norm weights."""
+    _copy_stages(arch, passport_model, model, strict=False)
+    for k in plkeys:
+        src, dst = _block(passport_model, arch, k), _block(model, arch, k)
+        dst.bn.weight.data.copy_(src.get_scale().view(-1))
+        dst.bn.bias.data.copy_(src.get_bias().view(-1))
+        if arch == 'alexnet':
+            dst.bn.weight.requires_grad_(True)
+            dst.bn.bias.requires_grad_(True)
+    if arch == 'alexnet':
+        _copy_hidden_classifier(passport_model, model)

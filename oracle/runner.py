@@ -151,3 +151,55 @@ def collect(case_name, impl, quiet=True):
     for k, v in sig.items():
         out['signature/' + k] = np.float64(v)
     return out
+
+
+def collect_shuttle(shuttle, with_keys=False):
+    """Weight-shuttle scenarios (reference experiments/utils.py:100-239), shared by the fixture generator (real
+    reference) and the tests (HIP build).  `shuttle` provides
+        plain(arch, ncls) / passport(arch, ncls, private) -> nn.Module on shuttle.device,
+        n2p(arch, plkeys, passport, plain), n2n(arch, new, old), p2n(arch, plkeys, passport, plain), plkeys(arch).
+    Every scenario's result is the digest of every tensor of the destination's state_dict.
+    with_keys=True adds the one scenario that needs the device kernels: passport -> plain with gamma/beta derived
+    from the keys."""
+    out = {}
+
+    def digest(tag, model):
+        for k, v in model.state_dict().items():
+            out[tag + '/' + k] = patterns.grad_digest(_np(v))
+
+    for arch in ('alexnet', 'resnet18'):
+        short = 'alexnet' if arch == 'alexnet' else 'resnet'
+        pk = shuttle.plkeys(arch)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        plain = patterns.fill_state(shuttle.plain(arch, 10), salt=3)
+        v1 = patterns.fill_state(shuttle.passport(arch, 10, False), salt=4)
+        shuttle.n2p(short, pk, v1, plain)
+        digest(arch + '_n2p_v1', v1)
+        private = patterns.fill_state(shuttle.passport(arch, 10, True), salt=4)
+        shuttle.n2p(short, pk, private, plain)
+        digest(arch + '_n2p_private', private)
+        back = patterns.fill_state(shuttle.plain(arch, 10), salt=5)
+        shuttle.p2n(short, pk, v1, back)               # v1 now carries learnable scale/bias: no kernels involved
+        digest(arch + '_p2n_learnable', back)
+        other = patterns.fill_state(shuttle.plain(arch, 100), salt=6)
+        shuttle.n2n(short, other, plain)
+        digest(arch + '_n2n', other)
+        if with_keys:
+            x, _ = patterns.batch(2, 3, 32, 32, 10)
+            keyed = shuttle.passport(arch, 10, False)
+            keyed.train()
+            with torch.no_grad():
+                keyed(x.to(shuttle.device))            # materialise key_type='random' keys
+            patterns.fill_state(keyed, salt=7)
+            for m in keyed.modules():
+                if hasattr(m, 'invalidate_key_cache'):
+                    m.invalidate_key_cache()
+            back = patterns.fill_state(shuttle.plain(arch, 10), salt=5)
+            shuttle.p2n(short, pk, keyed, back)
+            for k in pk:
+                name = ('features.%s' % k) if arch == 'alexnet' else k
+                sd = back.state_dict()
+                out[arch + '_p2n_keys/' + name + '.bn.weight'] = _np(sd[name + '.bn.weight'])
+                out[arch + '_p2n_keys/' + name + '.bn.bias'] = _np(sd[name + '.bn.bias'])
+    return out

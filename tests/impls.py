@@ -85,3 +85,50 @@ class ProductImpl:
     def test_signature(self, model):
         from deepipr_amd.experiments.trainer_private import TesterPrivate
         return TesterPrivate(model, self.device, verbose=False).test_signature()
+
+
+class ProductShuttle:
+    """deepipr_amd.experiments.utils weight shuttles on deepipr_amd's nets (oracle.runner.collect_shuttle)."""
+
+    def __init__(self, device='cpu'):
+        self.device = torch.device(device)
+
+    def _kw(self, arch):
+        from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+        from oracle.cases import alexnet_config, resnet18_config
+        cfg = alexnet_config() if arch == 'alexnet' else resnet18_config()
+        return construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn',
+                                                    'key_type': 'random', 'sl_ratio': ALPHA}, True)
+
+    def plkeys(self, arch):
+        return self._kw(arch)[1]
+
+    def plain(self, arch, ncls):
+        from deepipr_amd.models.alexnet_normal import AlexNetNormal
+        from deepipr_amd.models.resnet_normal import ResNet18
+        m = AlexNetNormal(3, ncls, 'bn') if arch == 'alexnet' else ResNet18(num_classes=ncls, norm_type='bn')
+        return m.to(self.device)
+
+    def passport(self, arch, ncls, private):
+        from deepipr_amd.models.alexnet_passport import AlexNetPassport
+        from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+        from deepipr_amd.models.resnet_passport import ResNet18Passport
+        from deepipr_amd.models.resnet_passport_private import ResNet18Private
+        kw = self._kw(arch)[0]
+        if arch == 'alexnet':
+            m = (AlexNetPassportPrivate if private else AlexNetPassport)(3, ncls, kw)
+        else:
+            m = (ResNet18Private if private else ResNet18Passport)(num_classes=ncls, passport_kwargs=kw)
+        return m.to(self.device)
+
+    def n2p(self, *a):
+        from deepipr_amd.experiments.utils import load_normal_model_to_passport_model
+        return load_normal_model_to_passport_model(*a)
+
+    def n2n(self, *a):
+        from deepipr_amd.experiments.utils import load_normal_model_to_normal_model
+        return load_normal_model_to_normal_model(*a)
+
+    def p2n(self, *a):
+        from deepipr_amd.experiments.utils import load_passport_model_to_normal_model
+        return load_passport_model_to_normal_model(*a)

@@ -59,3 +59,23 @@ def test_train_v23_backdoor_end_to_end(cpu_kernels, tmp_path):
     assert 'train_acc_public' in h and 'train_acc_private' in h and 'valid_total_acc' in h
     assert any(k.startswith('valid_s_private_features.') for k in h)
     assert out['logdir'].endswith(os.path.join('alexnet_cifar100_v3', '1'))
+
+
+def test_experiment_ids_best_checkpoint_and_eval(cpu_kernels, tmp_path, capsys):
+    """experiments/base.py:76-83,110-150: a run takes the smallest unused experiment id, writes best.pth next to
+    last.pth, and --eval --exp-id N evaluates that run's best.pth (warning when there is none)."""
+    sys.path.insert(0, ROOT)
+    import train_v1
+    common = ['--arch', 'alexnet', '--train-passport', '--key-type', 'random', '--batch-size', '4',
+              '--synthetic-samples', '8', '--device', 'cpu', '--logdir', str(tmp_path)]
+    first = train_v1.main(common + ['--epochs', '1'])
+    second = train_v1.main(common + ['--epochs', '1'])
+    assert first['logdir'].endswith(os.path.join('alexnet_cifar10_v1', '1'))
+    assert second['logdir'].endswith(os.path.join('alexnet_cifar10_v1', '2'))
+    for f in ('best.pth', 'last.pth'):
+        assert os.path.exists(os.path.join(second['logdir'], 'models', f))
+    res = train_v1.main(common + ['--eval', '--exp-id', '2'])
+    assert set(res) >= {'loss', 'acc'}
+    assert 'No such Experiment' not in capsys.readouterr().out
+    train_v1.main(common + ['--eval', '--exp-id', '9'])
+    assert 'No such Experiment' in capsys.readouterr().out

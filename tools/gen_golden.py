@@ -33,16 +33,19 @@ sys.path.insert(0, REF)
 
 from experiments.trainer import Trainer                              # noqa: E402
 from experiments.trainer_private import TesterPrivate, TrainerPrivate  # noqa: E402
-from experiments.utils import construct_passport_kwargs_from_dict    # noqa: E402
+from experiments.utils import (construct_passport_kwargs_from_dict, load_normal_model_to_normal_model,  # noqa: E402
+                               load_normal_model_to_passport_model, load_passport_model_to_normal_model)
+from models.alexnet_normal import AlexNetNormal                      # noqa: E402
 from models.alexnet_passport import AlexNetPassport                  # noqa: E402
 from models.alexnet_passport_private import AlexNetPassportPrivate   # noqa: E402
 from models.layers.passportconv2d import PassportBlock               # noqa: E402
 from models.layers.passportconv2d_private import PassportPrivateBlock  # noqa: E402
+from models.resnet_normal import ResNet18                            # noqa: E402
 from models.resnet_passport import ResNet18Passport                  # noqa: E402
 from models.resnet_passport_private import ResNet18Private           # noqa: E402
 
 from oracle import runner                                            # noqa: E402
-from oracle.cases import ALPHA, CASES                                # noqa: E402
+from oracle.cases import ALPHA, CASES, alexnet_config, resnet18_config   # noqa: E402
 
 
 class ReferenceImpl:
@@ -72,6 +75,31 @@ class ReferenceImpl:
 
     def test_signature(self, model):
         return TesterPrivate(model, self.device, verbose=False).test_signature()
+
+
+class ReferenceShuttle:
+    """The reference's weight shuttles (experiments/utils.py:100-239) on its own nets, CPU."""
+    device = torch.device('cpu')
+    n2p = staticmethod(load_normal_model_to_passport_model)
+    n2n = staticmethod(load_normal_model_to_normal_model)
+    p2n = staticmethod(load_passport_model_to_normal_model)
+
+    def _kw(self, arch):
+        cfg = alexnet_config() if arch == 'alexnet' else resnet18_config()
+        return construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn',
+                                                    'key_type': 'random', 'sl_ratio': ALPHA}, True)
+
+    def plkeys(self, arch):
+        return self._kw(arch)[1]
+
+    def plain(self, arch, ncls):
+        return AlexNetNormal(3, ncls, 'bn') if arch == 'alexnet' else ResNet18(num_classes=ncls, norm_type='bn')
+
+    def passport(self, arch, ncls, private):
+        kw = self._kw(arch)[0]
+        if arch == 'alexnet':
+            return (AlexNetPassportPrivate if private else AlexNetPassport)(3, ncls, kw)
+        return (ResNet18Private if private else ResNet18Passport)(num_classes=ncls, passport_kwargs=kw)
 
 
 def block_cases():
@@ -134,6 +162,27 @@ def block_cases():
         out['ckpt_private_out/y1'] = pv(xin, ind=1).numpy()
     out['ckpt_in/x'] = xin.numpy()
 
+    # force_passport (flip_attack.py:25, pruning_attack.py:26, passportconv2d.py:142-175): once a V1 block carries
+    # the learnable pair (init_scale/init_bias(True), as the weight shuttles do), plain calls use it and
+    # force_passport=True goes back to the key-derived gamma/beta and refreshes the sign loss
+    rs = np.random.RandomState(13)
+    out['force/scale'] = (1.0 + 0.5 * rs.standard_normal(16)).astype(np.float32)
+    out['force/bias'] = (0.5 * rs.standard_normal(16)).astype(np.float32)
+    v1.init_scale(True)
+    v1.init_bias(True)
+    with torch.no_grad():
+        v1.scale.copy_(torch.from_numpy(out['force/scale']))
+        v1.bias.copy_(torch.from_numpy(out['force/bias']))
+        out['force/v1_plain'] = v1(xin).numpy()
+        out['force/v1_plain_scale'] = v1.get_scale().numpy().reshape(-1)
+        v1.sign_loss.reset()
+        out['force/v1_forced'] = v1(xin, force_passport=True).numpy()
+        out['force/v1_forced_scale'] = v1.get_scale(True).numpy().reshape(-1)
+        out['force/v1_forced_bias'] = v1.get_bias(True).numpy().reshape(-1)
+        out['force/v1_forced_sign_loss'] = np.float64(v1.sign_loss.loss.item())
+        out['force/v1_forced_sign_acc'] = np.float64(float(v1.sign_loss.acc))
+        out['force/private_forced_ind0'] = pv(xin, force_passport=True, ind=0).numpy()
+
     # passport_selection is driven by python's `random` module
     cands = torch.arange(5 * 6 * 2 * 2, dtype=torch.float32).view(5, 6, 2, 2)
     random.seed(1234)
@@ -150,11 +199,16 @@ def block_cases():
 
 
 def main(argv):
-    names = argv or (list(CASES) + ['blocks'])
+    names = argv or (list(CASES) + ['blocks', 'shuttle'])
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     torch.set_num_threads(8)
     for name in names:
-        out = block_cases() if name == 'blocks' else runner.collect(name, ReferenceImpl())
+        if name == 'blocks':
+            out = block_cases()
+        elif name == 'shuttle':
+            out = runner.collect_shuttle(ReferenceShuttle(), with_keys=True)
+        else:
+            out = runner.collect(name, ReferenceImpl())
         path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
         np.savez_compressed(path, **{k.replace('/', '|'): v for k, v in out.items()})
         print('%-18s %4d arrays  %7.1f KB' % (name, len(out), os.path.getsize(path) / 1024))
