@@ -37,10 +37,9 @@ from deepipr_amd.models.resnet_passport import ResNet18Passport                 
 from deepipr_amd.models.resnet_passport_private import ResNet18Private             # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
-# algorithmic bytes per activation element; the BatchNorm-fused layer is the
-# default: stats 4 (read x), apply 8 (read x, write y), backward reduce 8 (read dy, x), backward apply 12
-BYTES_PER_ELT = {'bn_affine_bwd': 12, 'bn_affine_fwd': 8, 'bn_bwd_reduce': 8, 'bn_stats': 4,
-                 'affine_bwd': 12, 'affine_fwd': 8}
+# algorithmic bytes per activation element are accounted by the library per timed
+# launch: single-pass norm+affine+ReLU 8 forward / 12 backward; 3-launch form: stats 4, apply 8, backward sums 8,
+# backward apply 12; plain affine 8 / 12; SGD 20 per parameter
 
 
 def build_model(args, device):
@@ -161,18 +160,19 @@ def stress_roofline(device, reps=30):
     for _ in range(reps):
         once()
     torch.cuda.synchronize()
-    prof = _lib.profile_read()
+    prof, nbytes = _lib.profile_read(), _lib.profile_read_bytes()
     _lib.profile_enable(False)
-    el = x.numel()
     res = {}
-    for name, bpe in (('bn_affine_bwd', 12), ('bn_affine_fwd', 8), ('bn_bwd_reduce', 8), ('bn_stats', 4)):
+    for name in ('bn_res_bwd', 'bn_res_fwd', 'bn_affine_bwd', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_stats'):
         ms, cnt = prof[name]
-        us = 1000.0 * ms / cnt
-        res[name] = {'avg_us': round(us, 2), 'GBps': round(bpe * el / (us * 1e-6) / 1e9, 1)}
-    a = res['bn_affine_bwd']
-    return {'bound': 'hbm', 'kernel': 'k_bn_affine_bwd', 'shape': [n, c, h, w], 'achieved': a['GBps'],
+        if cnt:
+            res[name] = {'avg_us': round(1000.0 * ms / cnt, 2), 'GBps': round(nbytes[name] / (ms * 1e-3) / 1e9, 1),
+                         'bytes_per_launch': int(nbytes[name] / cnt)}
+    dom = 'bn_res_bwd' if 'bn_res_bwd' in res else 'bn_affine_bwd'
+    a = res[dom]
+    return {'bound': 'hbm', 'kernel': 'k_' + dom, 'shape': [n, c, h, w], 'achieved': a['GBps'],
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
-            'bytes_per_launch': 12 * el, 'avg_us': a['avg_us'], 'kernels': res}
+            'bytes_per_launch': a['bytes_per_launch'], 'avg_us': a['avg_us'], 'kernels': res}
 
 
 def pmc_traffic(kernel, shape_key):
@@ -272,6 +272,7 @@ def main():
     D.barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_read() if timing else {}
+    prof_bytes = _lib.profile_read_bytes() if timing else {}
     if timing:
         _lib.profile_enable(False)
     dt = D.max_over_ranks(dt, device)
@@ -304,52 +305,51 @@ def main():
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': 'hipGraph replay' if args.graph else 'eager'},
     }
-    dom = 'bn_affine_bwd' if prof.get('bn_affine_bwd', (0, 0))[1] > 0 else 'affine_bwd'
-    if timing and prof.get(dom, (0, 0))[1] > 0:
+    STREAMING = {'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt)',
+                 'bn_res_fwd': 'single-pass norm+affine+ReLU forward: read x once, write y (8 B/elt)',
+                 'bn_affine_bwd': 'norm+affine+ReLU backward apply pass: read dy + x, write dx (12 B/elt)',
+                 'bn_affine_fwd': 'norm+affine+ReLU forward apply pass (8 B/elt)',
+                 'bn_bwd_reduce': 'backward channel sums (8 B/elt)', 'bn_stats': 'batch statistics (4 B/elt)',
+                 'affine_bwd': 'affine backward: read dy + xhat, write dxhat (12 B/elt)',
+                 'affine_fwd': 'affine forward (8 B/elt)', 'sgd': 'fused SGD over the flat buffers (20 B/param)'}
+    if timing and any(prof.get(k, (0, 0))[1] > 0 for k in STREAMING):
         # Durations come from start/stop events attached to each kernel's own dispatch (hipExtLaunchKernelGGL):
-        # kernel execution time, comparable with rocprofv3's kernel trace.  The streaming kernels run once per
-        # fused layer call (passport layers AND BatchNorm ConvBlocks), so bytes and time are summed over all
-        # launches of the sampled steps: achieved = algorithmic bytes / kernel time.
+        # kernel execution time, comparable with rocprofv3's kernel trace.  The library also accounts the
+        # algorithmic bytes of every timed launch (deepipr_profile_read_bytes), so achieved = bytes / kernel time
+        # summed over exactly the launches that were timed.
         sampled = len(range(0, args.steps, stride))
-        tot_elems = float(sum(all_elems))
         kern = {}
-        for name, bpe in BYTES_PER_ELT.items():
+        for name in STREAMING:
             ms, n = prof.get(name, (0.0, 0))
             if n:
-                fused = name.startswith('bn_')
-                per_step = bpe * (tot_elems if fused else float(sum(elems)))
-                us_step = 1000.0 * ms / sampled
+                nbytes = prof_bytes.get(name, 0.0)
                 kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3),
-                              'us_per_step': round(us_step, 1), 'bytes_per_step': int(per_step),
-                              'GBps': round(per_step / (us_step * 1e-6) / 1e9, 1)}
+                              'us_per_step': round(1000.0 * ms / sampled, 1),
+                              'bytes_per_step': int(nbytes / sampled),
+                              'GBps': round(nbytes / (ms * 1e-3) / 1e9, 1)}
                 kern[name]['frac'] = round(kern[name]['GBps'] / HBM_PEAK_GBS, 4)
-        ms, n = prof.get('sgd', (0.0, 0))
-        if n:
-            nparam = sum(p.numel() for p in model.parameters())
-            us = 1000.0 * ms / n
-            kern['sgd'] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(us, 3),
-                           'bytes_per_step': 20 * nparam, 'GBps': round(20 * nparam / (us * 1e-6) / 1e9, 1)}
-            kern['sgd']['frac'] = round(kern['sgd']['GBps'] / HBM_PEAK_GBS, 4)
-        for name in ('gamma_beta_fwd', 'passport_bwd_finish', 'reduce_partials'):
+        for name in ('gamma_beta_fwd', 'gamma_beta_bwd', 'passport_bwd_finish', 'reduce_partials'):
             ms, n = prof.get(name, (0, 0))
             if n:
-                kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3)}
+                kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3),
+                              'us_per_step': round(1000.0 * ms / sampled, 1)}
+        # dominant kernel = the passport/norm streaming kernel with the most time per step
+        dom = max((k for k in kern if k in STREAMING and k != 'sgd'), key=lambda k: kern[k]['us_per_step'])
         a = kern[dom]
         per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s backward pass: read dy + x, write dx)' % (
-                               dom, 'norm+affine+ReLU' if dom.startswith('bn') else 'affine'),
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
-                           'traffic': None, 'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
+                           'traffic': pmc_traffic('k_' + dom, 'in_situ_per_launch'),
+                           'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
                            'launches_per_step': a['launches_per_step'],
-                           'note': '12 B/elt; %d launches per step over activations of %.1f-%.1f MB (%d passport '
-                                   'layer calls of %.1f MB among them); PMC traffic = algorithmic bytes within 1 %% '
-                                   '(profiles/pmc_traffic.json)' % (
-                                       len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
-                                       len(elems), 4 * float(np.mean(elems)) / 1e6)}
+                           'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '
+                                   'layer calls of %.1f MB among them); bytes and time summed over the timed '
+                                   'launches' % (len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
+                                                 len(elems), 4 * float(np.mean(elems)) / 1e6)}
         out['kernels'] = kern
         if args.gpus == 1 and not args.no_stress:
             out['roofline_stress'] = stress_roofline(device)
-            out['roofline_stress']['traffic'] = pmc_traffic('k_' + dom, 'S3[512,512,8,8]')
+            out['roofline_stress']['traffic'] = pmc_traffic(out['roofline_stress']['kernel'], 'S3[512,512,8,8]')
     if args.gpus == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

@@ -49,12 +49,16 @@ SIGNATURES = {
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
                                        _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,
-                                       _f32p, _f32p, _i8p, _vp, _vp]),
+                                       _f32p, _f32p, _i8p, _vp, _vp, _vp]),
     'deepipr_passport_bn_bwd': (_int, [_f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _f32p,
                                        _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _vp,
-                                       _vp]),
+                                       _vp, _vp]),
+    'deepipr_set_resident': (_int, [_int]),
+    'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
+SYNC_WORDS = 4096 + 16           # DEEPIPR_SYNC_WORDS
+SYNC_TIMEOUT_WORD = 4096        # DEEPIPR_SYNC_TIMEOUT_WORD
 
 
 class HipLibraryMissing(RuntimeError):
@@ -99,7 +103,13 @@ def check(rc, what):
 
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
-                   'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu']
+                   'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
+                   'bn_res_bwd']
+
+
+def set_resident(on):
+    """Enable (default) / disable the register-resident single-pass BatchNorm kernels process-wide."""
+    check(lib().deepipr_set_resident(int(bool(on))), 'set_resident')
 
 
 def profile_enable(on):
@@ -114,4 +124,14 @@ def profile_read():
         ms, n = ctypes.c_double(), ctypes.c_longlong()
         check(lib().deepipr_profile_read(i, ctypes.byref(ms), ctypes.byref(n)), 'profile_read')
         out[name] = (ms.value, n.value)
+    return out
+
+
+def profile_read_bytes():
+    """{kernel name: algorithmic HBM bytes of the launches timed so far} (streaming kernels; 0 for the rest)."""
+    out = {}
+    for i, name in enumerate(PROFILE_KERNELS):
+        v = ctypes.c_double()
+        check(lib().deepipr_profile_read_bytes(i, ctypes.byref(v)), 'profile_read_bytes')
+        out[name] = v.value
     return out

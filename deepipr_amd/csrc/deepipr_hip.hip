@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -63,10 +64,11 @@ struct ProfState {
     std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> pool;
-    struct Pending { int k; hipEvent_t a, b; };
+    struct Pending { int k; hipEvent_t a, b; double bytes; };
     std::vector<Pending> pending;
     double total_ms[DEEPIPR_PROFILE_KERNELS] = {};
     long long launches[DEEPIPR_PROFILE_KERNELS] = {};
+    double total_bytes[DEEPIPR_PROFILE_KERNELS] = {};   // algorithmic bytes of the timed launches
 };
 ProfState g_prof;
 
@@ -74,6 +76,7 @@ struct ProfScope {
     int k;
     hipEvent_t a = nullptr, b = nullptr;
     bool used = false;
+    double bytes = 0.0;             // algorithmic HBM bytes of this launch (streaming kernels set it)
     ProfScope(int kernel, hipStream_t) : k(kernel) {
         if (!g_prof.on) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -90,7 +93,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!a) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (used) g_prof.pending.push_back({k, a, b});
+        if (used) g_prof.pending.push_back({k, a, b, bytes});
         else { g_prof.pool.push_back(a); g_prof.pool.push_back(b); }
     }
 };
@@ -1254,6 +1257,321 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 
 
 // ============================================================================================
+// Register-resident single-pass form of the BatchNorm-fused layer.
+//
+// 256 CUs hold 128 MB of vector registers -- more than any activation of the CIFAR-shape nets (33.5 MB at most).
+// When a layer's x (backward: dy and x) fits, every workgroup loads its slice ONCE into registers, the channel
+// sums are formed, and y (dx) is computed from the registers: 8 B/element forward and 12 B/element backward
+// instead of 12 and 20, and one launch instead of three.
+//   * workgroup = (channel group cb, batch slice s): G adjacent channels (G > 1 only for planes shorter than a
+//     128-byte line) x `nps` samples; thread t keeps float4 units t, t+T, ... (F4 of them, a template constant);
+//   * S == 1: the workgroup owns its channels outright, nothing leaves the CU between the two phases;
+//   * S > 1 (fewer channels than CUs): the S workgroups of a channel exchange their two partial sums in-launch:
+//     write-through (sc1) stores -> vmcnt drain -> relaxed agent-scope ticket on sync[cb]; one lane polls the
+//     ticket word relaxed and reads the S partials back with sc1 loads, summed in slice order (every partner
+//     gets bit-identical statistics).  Each call adds exactly 64 to sync[cb] (each slice adds 64/S), so the word
+//     needs no reset: it only has to be a multiple of 64 -- zero once -- when a call starts.  All S*CB workgroups
+//     must be co-resident: the host only takes this path with T = 1024 and a grid <= the CU count, on a device it
+//     does not share with a concurrent kernel (the caller withholds `sync` otherwise); the spin is bounded and
+//     reports through sync[kSyncTimeoutWord].
+// Fixed-order sums throughout: bit-reproducible run to run.
+// ============================================================================================
+constexpr int kSyncCounters = 4096;
+constexpr int kSyncTimeoutWord = kSyncCounters;
+constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(4): a few seconds
+
+struct ResPlan {
+    int T, F4;            // threads per workgroup, float4 units per thread
+    int S, nps;           // batch slices per channel group, samples per slice
+    int G, q4, gq;        // channels per workgroup, float4 per plane, G*q4
+    int blocks;           // (C/G) * S
+    FastDiv gqdiv;
+};
+
+__device__ __forceinline__ void sc1_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double sc1_load(const double *p) {
+    return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+// Per-local-channel sums of (a, b) over the workgroup; every thread gets the sums of ITS channel.
+// red: 2 * (T/64) * 8 doubles of LDS.
+template <int T>
+__device__ __forceinline__ void res_block_sums(double &a, double &b, const ResPlan &pl, int c_local, double *red) {
+    constexpr int NW = T / kWave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (pl.G == 1) {
+        a = wave_sum(a);
+        b = wave_sum(b);
+    } else {                                   // lanes with equal (lane % gq) / q4 share a channel
+        for (int off = kWave / 2; off >= pl.gq; off >>= 1) {
+            a += __shfl_xor(a, off, kWave);
+            b += __shfl_xor(b, off, kWave);
+        }
+        for (int off = pl.q4 >> 1; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, kWave);
+            b += __shfl_xor(b, off, kWave);
+        }
+    }
+    __syncthreads();
+    if (lane < pl.gq && lane == c_local * pl.q4) {          // first lane of each local channel (G == 1: lane 0)
+        red[(wave * 8 + c_local) * 2 + 0] = a;
+        red[(wave * 8 + c_local) * 2 + 1] = b;
+    }
+    __syncthreads();
+    a = 0.0;
+    b = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        a += red[(w * 8 + c_local) * 2 + 0];
+        b += red[(w * 8 + c_local) * 2 + 1];
+    }
+}
+
+// In-launch exchange of one channel's two partial sums between its S slice workgroups (thread 0 only).
+__device__ __forceinline__ void res_exchange(double &s0, double &s1, double *part, int C, int c, int s, int S,
+                                             unsigned *sync, int cb) {
+    sc1_store(part + (static_cast<size_t>(s) * 2 + 0) * C + c, s0);
+    sc1_store(part + (static_cast<size_t>(s) * 2 + 1) * C + c, s1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(sync + cb, 64u / static_cast<unsigned>(S), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (ticket & ~63u) + 64u;
+    unsigned spins = 0;
+    while (static_cast<int>(__hip_atomic_load(sync + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kSpinLimit) {
+            __hip_atomic_store(sync + kSyncTimeoutWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    double t0 = 0.0, t1 = 0.0;
+    for (int sp = 0; sp < S; ++sp) {
+        t0 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 0) * C + c);
+        t1 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 1) * C + c);
+    }
+    s0 = t0;
+    s1 = t1;
+}
+
+template <int T>
+__device__ __forceinline__ void sign_loss_block_t(const float *__restrict__ gamma, const SignArgs &sa, int C,
+                                                  double *red /* >= 3 * T/64 doubles */) {
+    constexpr int NW = T / kWave;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int c = threadIdx.x; c < C; c += T) {
+        const float g = gamma[c], bb = sa.b[c];
+        const float z = __fadd_rn(__fmul_rn(-bb, g), sa.margin);
+        v[0] += static_cast<double>(__fmul_rn(sa.alpha, fmaxf(z, 0.0f)));
+        v[1] += static_cast<double>(__fmul_rn(g, g));
+        const int sg = (g > 0.0f) - (g < 0.0f);
+        const int sb = (bb > 0.0f) - (bb < 0.0f);
+        v[2] += (sg == sb) ? 1.0 : 0.0;
+        if (sa.bits) sa.bits[c] = static_cast<int8_t>(sg);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] = wave_sum(v[i]);
+        if ((threadIdx.x & 63) == 0) red[i * NW + (threadIdx.x >> 6)] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int i = 0; i < 3; ++i)
+            for (int w = 0; w < NW; ++w) t[i] += red[i * NW + w];
+        if (sa.loss) *sa.loss = static_cast<float>(t[0] + static_cast<double>(sa.l2) * t[1]);
+        if (sa.acc) *sa.acc = static_cast<float>(t[2] / static_cast<double>(C));
+    }
+}
+
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_fwd(
+    const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
+    const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
+    unsigned *sync, int with_sign, SignArgs sa) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ float4 chan[8];
+    __shared__ double xch[2];
+    if (with_sign && static_cast<int>(blockIdx.x) == pl.blocks) {
+        sign_loss_block_t<T>(gamma, sa, C, red);
+        return;
+    }
+    const int t = threadIdx.x;
+    const int cb = blockIdx.x / pl.S, s = blockIdx.x - cb * pl.S;
+    const int c0 = cb * pl.G;
+    const int n0 = s * pl.nps;
+    const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
+    const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
+    float4 v[F4];
+    unsigned idx[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        idx[k] = 0;
+        if (j < units) {
+            const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
+            idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
+            v[k] = x[idx[k]];
+        }
+    }
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        a0 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        a1 = fmaf(v[k].x, v[k].x, a1);
+        a1 = fmaf(v[k].y, v[k].y, a1);
+        a1 = fmaf(v[k].z, v[k].z, a1);
+        a1 = fmaf(v[k].w, v[k].w, a1);
+    }
+    double s1 = static_cast<double>(a0), s2 = static_cast<double>(a1);
+    res_block_sums<T>(s1, s2, pl, c_local, red);
+    if (pl.S > 1) {                                   // G == 1 here
+        if (t == 0) {
+            res_exchange(s1, s2, part, C, c0, s, pl.S, sync, cb);
+            xch[0] = s1;
+            xch[1] = s2;
+        }
+        __syncthreads();
+        s1 = xch[0];
+        s2 = xch[1];
+    }
+    if (t < pl.gq && t == c_local * pl.q4) {          // one thread per local channel
+        const int c = c0 + c_local;
+        const double mu = s1 * f.inv_m;
+        double var = s2 * f.inv_m - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mean = static_cast<float>(mu);
+        const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
+        const float g = gamma[c], bt = beta[c];
+        chan[c_local] = make_float4(mean, invstd, g, bt);
+        if (s == 0) {
+            if (f.running_mean) {
+                f.running_mean[c] = (1.0f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+                f.running_var[c] = (1.0f - f.momentum) * f.running_var[c] +
+                                   f.momentum * static_cast<float>(var * f.unbias);
+            }
+            float4 *row = reinterpret_cast<float4 *>(f.tbl + static_cast<size_t>(c) * kTbl);
+            row[0] = make_float4(mean, invstd, g, bt);
+            row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    if (blockIdx.x == 0 && t == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+    __syncthreads();
+    const float4 ch = chan[c_local];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        if (j < units) {
+            float4 o;
+            if (relu) {
+                o = make_float4(bn_affine1<true>(v[k].x, ch), bn_affine1<true>(v[k].y, ch),
+                                bn_affine1<true>(v[k].z, ch), bn_affine1<true>(v[k].w, ch));
+            } else {
+                o = make_float4(bn_affine1<false>(v[k].x, ch), bn_affine1<false>(v[k].y, ch),
+                                bn_affine1<false>(v[k].z, ch), bn_affine1<false>(v[k].w, ch));
+            }
+            y[idx[k]] = o;
+        }
+    }
+}
+
+struct ResBwdArgs {
+    const float *b;                 // signature bits (sign loss), may be nullptr
+    float alpha, margin, l2;
+    const float *dloss, *dgamma_extra, *dbeta_extra;
+    float *dgamma, *dbeta;
+    double inv_m;                   // 1/(N*HW); 0 in evaluation mode
+};
+
+__device__ __forceinline__ void res_bwd_prep(float d, float xv, const float4 &ch, int relu, float &dz, float &xh) {
+    xh = (xv - ch.x) * ch.y;
+    dz = d;
+    if (relu) dz = (__fadd_rn(__fmul_rn(ch.z, xh), ch.w) > 0.0f) ? d : 0.0f;
+}
+
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_bwd(
+    const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
+    float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, double *part, unsigned *sync, ResBwdArgs a) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[2];
+    const int t = threadIdx.x;
+    const int cb = blockIdx.x / pl.S, s = blockIdx.x - cb * pl.S;
+    const int c0 = cb * pl.G;
+    const int n0 = s * pl.nps;
+    const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
+    const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
+    float4 dz[F4], xh[F4];
+    unsigned idx[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        dz[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        xh[k] = make_float4(ch.x, ch.x, ch.x, ch.x);          // -> xhat 0 for the unused units
+        idx[k] = 0;
+        if (j < units) {
+            const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
+            idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
+            dz[k] = dy[idx[k]];
+            xh[k] = x[idx[k]];
+        }
+    }
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        float4 d = dz[k], v = xh[k];
+        res_bwd_prep(d.x, v.x, ch, relu, dz[k].x, xh[k].x);
+        res_bwd_prep(d.y, v.y, ch, relu, dz[k].y, xh[k].y);
+        res_bwd_prep(d.z, v.z, ch, relu, dz[k].z, xh[k].z);
+        res_bwd_prep(d.w, v.w, ch, relu, dz[k].w, xh[k].w);
+        a0 = fmaf(dz[k].x, xh[k].x, a0);
+        a0 = fmaf(dz[k].y, xh[k].y, a0);
+        a0 = fmaf(dz[k].z, xh[k].z, a0);
+        a0 = fmaf(dz[k].w, xh[k].w, a0);
+        a1 += (dz[k].x + dz[k].y) + (dz[k].z + dz[k].w);
+    }
+    double ag = static_cast<double>(a0), ab = static_cast<double>(a1);
+    res_block_sums<T>(ag, ab, pl, c_local, red);
+    if (pl.S > 1) {
+        if (t == 0) {
+            res_exchange(ag, ab, part, C, c0, s, pl.S, sync, cb);
+            xch[0] = ag;
+            xch[1] = ab;
+        }
+        __syncthreads();
+        ag = xch[0];
+        ab = xch[1];
+    }
+    if (s == 0 && t < pl.gq && t == c_local * pl.q4) {
+        const int c = c0 + c_local;
+        float dg = static_cast<float>(ag), db = static_cast<float>(ab);
+        if (a.dgamma_extra) dg += a.dgamma_extra[c];
+        if (a.dbeta_extra) db += a.dbeta_extra[c];
+        if (a.dloss) dg += a.dloss[0] * sign_loss_grad1(ch.z, a.b[c], a.alpha, a.margin, a.l2);
+        a.dgamma[c] = dg;
+        a.dbeta[c] = db;
+    }
+    const float c2 = static_cast<float>(ab * a.inv_m), c3 = static_cast<float>(ag * a.inv_m);
+    const float sc = ch.z * ch.y;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        if (j < units) {
+            dx[idx[k]] = make_float4(sc * (dz[k].x - c2 - xh[k].x * c3), sc * (dz[k].y - c2 - xh[k].y * c3),
+                                     sc * (dz[k].z - c2 - xh[k].z * c3), sc * (dz[k].w - c2 - xh[k].w * c3));
+        }
+    }
+}
+
+// ============================================================================================
 // SGD with momentum and weight decay over one flat parameter buffer (experiments/classification.py:47-50:
 // optim.SGD(lr, momentum=0.9, weight_decay=1e-4); torch semantics: g += wd*p; buf = mu*buf + g; p -= lr*buf).
 // One streaming pass: reads p, g, buf and writes p, buf = 20 B per parameter.  `grad_scale` folds the
@@ -1340,6 +1658,7 @@ int launch_affine_fwd(const float *xhat, const float *gamma, const float *beta, 
     if (total >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "affine_relu_fwd: tensor has >= 2^31 elements");
     const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
     ProfScope prof(DEEPIPR_K_AFFINE_FWD, st);
+    prof.bytes = 8.0 * static_cast<double>(total);
     const bool vec = (HW % 4 == 0) && aligned16(xhat) && aligned16(y);
     if (vec) {
         const unsigned n4 = static_cast<unsigned>(total / 4);
@@ -1398,6 +1717,7 @@ int launch_affine_bwd(const float *dy, const float *xh, const float *g, const fl
     const BwdPlan pl = plan_bwd(N, C, P, can_vec);
     if (pl.NS > 65535) return fail(DEEPIPR_EINVAL, "affine_relu_bwd: too many batch splits");
     ProfScope prof(DEEPIPR_K_AFFINE_BWD, st);
+    prof.bytes = 12.0 * static_cast<double>(N) * C * P;
     if (pl.VEC == 4) {
         if (relu) launch_bwd_t<4, true>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
         else launch_bwd_t<4, false>(prof, dy, xh, g, bt, dx, part, N, C, P, pl, st);
@@ -1432,28 +1752,44 @@ const char *deepipr_last_error(void) { return g_err; }
 int deepipr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (on == 1) {                                   // 1 = start afresh, 2 = resume, 0 = pause
-        for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) { g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; }
+        for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) { g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; g_prof.total_bytes[i] = 0.0; }
     }
     g_prof.on = on != 0;
     return DEEPIPR_OK;
 }
 
-int deepipr_profile_read(int kernel, double *total_ms, long long *launches) {
-    if (kernel < 0 || kernel >= DEEPIPR_PROFILE_KERNELS || !total_ms || !launches)
-        return fail(DEEPIPR_EINVAL, "profile_read: bad argument");
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    for (auto &p : g_prof.pending) {           // drain everything recorded so far
+namespace {
+void prof_drain_locked() {                         // everything recorded so far
+    for (auto &p : g_prof.pending) {
         float ms = 0.0f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             g_prof.total_ms[p.k] += ms;
             g_prof.launches[p.k] += 1;
+            g_prof.total_bytes[p.k] += p.bytes;
         }
         g_prof.pool.push_back(p.a);
         g_prof.pool.push_back(p.b);
     }
     g_prof.pending.clear();
+}
+}  // namespace
+
+int deepipr_profile_read(int kernel, double *total_ms, long long *launches) {
+    if (kernel < 0 || kernel >= DEEPIPR_PROFILE_KERNELS || !total_ms || !launches)
+        return fail(DEEPIPR_EINVAL, "profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain_locked();
     *total_ms = g_prof.total_ms[kernel];
     *launches = g_prof.launches[kernel];
+    return DEEPIPR_OK;
+}
+
+int deepipr_profile_read_bytes(int kernel, double *total_bytes) {
+    if (kernel < 0 || kernel >= DEEPIPR_PROFILE_KERNELS || !total_bytes)
+        return fail(DEEPIPR_EINVAL, "profile_read_bytes: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain_locked();
+    *total_bytes = g_prof.total_bytes[kernel];
     return DEEPIPR_OK;
 }
 
@@ -1652,6 +1988,7 @@ int launch_walk(const float *dy, const float *x, const float *tbl, double *part,
     const BwdPlan pl = plan_bwd(N, C, P, can_vec);
     if (pl.NS > 65535) return fail(DEEPIPR_EINVAL, "bn walk: too many batch splits");
     ProfScope prof(MODE == WALK_STATS ? DEEPIPR_K_BN_STATS : DEEPIPR_K_BN_BWD_REDUCE, st);
+    prof.bytes = (MODE == WALK_STATS ? 4.0 : 8.0) * static_cast<double>(N) * C * P;
     if (pl.VEC == 4) {
         if (relu) launch_walk_t<MODE, 4, true>(prof, dy, x, tbl, part, N, C, P, pl, st);
         else launch_walk_t<MODE, 4, false>(prof, dy, x, tbl, part, N, C, P, pl, st);
@@ -1663,13 +2000,131 @@ int launch_walk(const float *dy, const float *x, const float *tbl, double *part,
     return check_launch("bn walk");
 }
 
+
+// ---- register-resident path: planning and launch ----
+std::atomic<int> g_resident_mode{1};
+
+int device_cu_count() {
+    static std::mutex mu;
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cache[dev] = n > 0 ? n : -1;
+    }
+    return cache[dev] > 0 ? cache[dev] : 0;
+}
+
+// Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread of a 1024-thread workgroup may keep.
+bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out) {
+    if (g_resident_mode.load(std::memory_order_relaxed) == 0 || P % 4 != 0) return false;
+    const int cus = device_cu_count();
+    if (cus <= 0) return false;
+    ResPlan pl{};
+    pl.q4 = P / 4;
+    int G = 1;
+    if ((pl.q4 & (pl.q4 - 1)) == 0 && pl.q4 < 8) {           // planes shorter than a 128-byte line
+        G = 8 / pl.q4;
+        while (G > 1 && C % G != 0) G >>= 1;
+    }
+    auto slices = [&](int cb) {                  // split channels only when they cover less than half the CUs:
+        int S = 1;                               // 128 workgroups already stream as fast as 256 with the exchange
+        if (can_sync && cb * 2 < cus)
+            while (S < 64 && cb * (S * 2) <= cus && S * 2 <= N) S *= 2;
+        return S;
+    };
+    int S = slices(C / G);
+    if (S > 1 && G > 1) {
+        G = 1;
+        S = slices(C);
+    }
+    if (S > 1 && C > kSyncCounters) S = 1;
+    pl.G = G;
+    pl.gq = G * pl.q4;
+    pl.S = S;
+    pl.nps = (N + S - 1) / S;
+    pl.blocks = (C / G) * S;
+    const long long units = static_cast<long long>(pl.nps) * pl.gq;
+    pl.T = (S == 1 && units <= 8 * 256) ? 256 : 1024;
+    if (pl.blocks * 4 < cus) return false;                   // too few workgroups to be worth a single pass
+    const long long need = (units + pl.T - 1) / pl.T;
+    static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    pl.F4 = 0;
+    for (int f : steps)
+        if (f >= need && f <= (pl.T == 256 ? 8 : max_f4)) {
+            pl.F4 = f;
+            break;
+        }
+    if (pl.F4 == 0) return false;
+    pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
+    *out = pl;
+    return true;
+}
+
+#define DEEPIPR_RES_CASES(KERNEL, TT, ...)                                                                        \
+    switch (pl.F4) {                                                                                              \
+        case 1: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 1>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 2: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 2>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 3: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 3>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 4: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 4>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 6: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 6>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        default: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 8>), grid, dim3(TT), st, __VA_ARGS__); break;                   \
+    }
+
+int launch_res_fwd(const float *x, float *y, const float *gamma, const float *beta, int relu, int N, int C,
+                   const ResPlan &pl, const BnFinishArgs &f, double *part, unsigned *sync, bool with_sign,
+                   const SignArgs &sa, hipStream_t st) {
+    ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
+    prof.bytes = 8.0 * static_cast<double>(N) * C * pl.q4 * 4;
+    const dim3 grid(pl.blocks + (with_sign ? 1 : 0));
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    const int ws = with_sign ? 1 : 0;
+    if (pl.T == 256) {
+        DEEPIPR_RES_CASES(k_bn_res_fwd, 256, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa)
+    } else if (pl.F4 == 12) {
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa);
+    } else if (pl.F4 == 16) {
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 16>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa);
+    } else {
+        DEEPIPR_RES_CASES(k_bn_res_fwd, 1024, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa)
+    }
+    return check_launch("passport_bn_fwd(resident)");
+}
+
+int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
+                   const ResPlan &pl, double *part, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
+    ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
+    prof.bytes = 12.0 * static_cast<double>(N) * C * pl.q4 * 4;
+    const dim3 grid(pl.blocks);
+    const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *o4 = reinterpret_cast<float4 *>(dx);
+    if (pl.T == 256) {
+        DEEPIPR_RES_CASES(k_bn_res_bwd, 256, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
+    } else {
+        DEEPIPR_RES_CASES(k_bn_res_bwd, 1024, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
+    }
+    return check_launch("passport_bn_bwd(resident)");
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW) {
     if (bad_dims(N, C, HW)) return 0;
-    return bwd_workspace_bytes(N, C, HW);
+    const size_t two_pass = bwd_workspace_bytes(N, C, HW);
+    const size_t resident = static_cast<size_t>(64) * 2 * C * sizeof(double);      // up to 64 batch slices
+    return two_pass > resident ? two_pass : resident;
+}
+
+int deepipr_set_resident(int mode) {
+    if (mode != 0 && mode != 1) return fail(DEEPIPR_EINVAL, "set_resident: mode must be 0 or 1");
+    g_resident_mode.store(mode);
+    return DEEPIPR_OK;
 }
 
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
@@ -1677,7 +2132,7 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
                             float *running_mean, float *running_var, long long *num_batches_tracked,
                             float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
                             float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
-                            int8_t *bits, void *workspace, void *stream) {
+                            int8_t *bits, void *workspace, unsigned int *sync, void *stream) {
     if (!x || !y || !table || bad_dims(N, C, HW)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: bad argument");
     if (W && (!m || !gamma || !beta || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: W needs m, gamma, beta, K");
     if (!W && (!gamma_in || !beta_in)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: need W or gamma_in/beta_in");
@@ -1694,13 +2149,6 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
     double *part = static_cast<double *>(workspace);
     BnFinishArgs f{};
     const double M = static_cast<double>(N) * HW;
-    if (training) {
-        BwdPlan pl;
-        int rc = launch_walk<WALK_STATS>(nullptr, x, nullptr, part, N, C, HW, relu, &pl, st);
-        if (rc != DEEPIPR_OK) return rc;
-        f.part = part;
-        f.NS = pl.NS;
-    }
     f.inv_m = 1.0 / M;
     f.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
     f.eps = eps;
@@ -1709,6 +2157,28 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
     f.running_var = running_var;
     f.num_batches_tracked = num_batches_tracked;
     f.tbl = table;
+    ResPlan rp;
+    if (training && aligned16(x) && aligned16(y) && plan_resident(N, C, HW, 16, sync != nullptr, &rp)) {
+        // single pass: x stays in registers between the statistics and the normalise/affine/ReLU phase
+        const float *g = gamma_in, *bt = beta_in;
+        if (W) {
+            int rc = deepipr_gamma_beta_fwd(W, m, C, K, gamma, beta, stream);
+            if (rc != DEEPIPR_OK) return rc;
+            g = gamma;
+            bt = beta;
+        }
+        f.part = part;
+        f.NS = rp.S;
+        SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
+        return launch_res_fwd(x, y, g, bt, relu, N, C, rp, f, part, sync, with_sign, sa, st);
+    }
+    if (training) {
+        BwdPlan pl;
+        int rc = launch_walk<WALK_STATS>(nullptr, x, nullptr, part, N, C, HW, relu, &pl, st);
+        if (rc != DEEPIPR_OK) return rc;
+        f.part = part;
+        f.NS = pl.NS;
+    }
     const float *g_for_sign = gamma_in;
     {
         ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
@@ -1732,6 +2202,7 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
     SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
     const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
     ProfScope prof(DEEPIPR_K_BN_AFFINE_FWD, st);
+    prof.bytes = 8.0 * static_cast<double>(total);
     if (HW % 4 == 0 && aligned16(x) && aligned16(y)) {
         const unsigned n4 = static_cast<unsigned>(total / 4);
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW / 4));
@@ -1773,7 +2244,7 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                             float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
-                            void *stream) {
+                            unsigned int *sync, void *stream) {
     if (!dy || !x || !table || !dx || !dgamma || !dbeta || !table_out || !workspace || bad_dims(N, C, HW))
         return fail(DEEPIPR_EINVAL, "passport_bn_bwd: bad argument");
     if (dW && (!m || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: dW needs m and K");
@@ -1782,6 +2253,15 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
     if (total >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tensor has >= 2^31 elements");
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *part = static_cast<double *>(workspace);
+    ResPlan rp;
+    if (aligned16(x) && aligned16(dy) && aligned16(dx) && plan_resident(N, C, HW, 8, sync != nullptr, &rp)) {
+        // single pass: dz and xhat stay in registers between the two channel sums and the dx phase
+        ResBwdArgs a{b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, dgamma, dbeta,
+                     training ? 1.0 / (static_cast<double>(N) * HW) : 0.0};
+        int rc = launch_res_bwd(dy, x, table, dx, relu, N, C, rp, part, sync, a, st);
+        if (rc != DEEPIPR_OK) return rc;
+        return dW ? deepipr_gamma_beta_bwd(dgamma, dbeta, m, C, K, dW, stream) : DEEPIPR_OK;
+    }
     BwdPlan pl;
     int rc = launch_walk<WALK_BN_BWD>(dy, x, table, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
@@ -1804,6 +2284,7 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
     }
     const FastDiv cdiv = make_fastdiv(static_cast<unsigned>(C));
     ProfScope prof(DEEPIPR_K_BN_AFFINE_BWD, st);
+    prof.bytes = 12.0 * static_cast<double>(total);
     if (HW % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx)) {
         const unsigned n4 = static_cast<unsigned>(total / 4);
         const FastDiv pdiv = make_fastdiv(static_cast<unsigned>(HW / 4));
@@ -1845,6 +2326,7 @@ int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_b
     if (!param || !grad || !momentum_buf || n == 0) return fail(DEEPIPR_EINVAL, "sgd_momentum_step: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DEEPIPR_K_SGD, st);
+    prof.bytes = 20.0 * static_cast<double>(n);
     if (n % 4 == 0 && aligned16(param) && aligned16(grad) && aligned16(momentum_buf)) {
         const size_t n4 = n / 4;
         DEEPIPR_LAUNCH(prof, k_sgd_momentum_v4, dim3(grid_for(n4)), dim3(kThreads), st, reinterpret_cast<float4 *>(param),

@@ -78,6 +78,8 @@ def replicate(model, device, bucket_mb=BUCKET_MB, static_graph=True):
         return model
     check_keys_materialised(model)
     broadcast_state(model, 0)
+    from deepipr_amd import passport_ops
+    passport_ops.kernels.allow_sync = False   # DDP's bucket all-reduces share the device with backward
     ids = [device.index] if device.type == 'cuda' else None
     return torch.nn.parallel.DistributedDataParallel(
         model, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
@@ -93,7 +95,10 @@ def max_over_ranks(value, device):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])      # no guessing which GPU the barrier runs on
+        else:
+            dist.barrier()
 
 
 def shutdown():

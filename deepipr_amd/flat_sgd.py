@@ -37,6 +37,8 @@ class FlatSGD(torch.optim.Optimizer):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # DEEPIPR_FORCE_DDP=1: run the bucketed exchange even in a world of one (single-GPU rehearsal of the N>1 path)
         self.comm = self.world > 1 or (dist.is_initialized() and os.environ.get('DEEPIPR_FORCE_DDP') == '1')
+        if self.comm:
+            P.kernels.allow_sync = False      # collectives share the device: no co-residency-dependent kernels
         plist = self.param_groups[0]['params']
         if len(self.param_groups) != 1:
             raise ValueError('FlatSGD keeps one parameter group (one lr / momentum / weight decay)')

@@ -221,6 +221,26 @@ class HipKernels:
             self._arena[key] = buf
         return buf.data_ptr()
 
+    # In-launch exchange words of the register-resident kernels (include/deepipr_hip.h, DEEPIPR_SYNC_WORDS): one
+    # zero-initialised buffer per (device, stream), owned by the library afterwards.  `allow_sync` is cleared by
+    # whoever runs kernels on a second stream of the same device (FlatSGD / DDP gradient exchange): the split-channel
+    # form needs every workgroup co-resident, which a concurrent collective can delay.
+    _sync = {}
+    allow_sync = True
+
+    def _sync_words(self, dev, stream):
+        if not self.allow_sync:
+            return None
+        key = (dev.index, stream)
+        buf = self._sync.get(key)
+        if buf is None:
+            buf = self._sync[key] = torch.zeros(_lib.SYNC_WORDS, dtype=torch.int32, device=dev)
+        return buf.data_ptr()
+
+    def sync_timeouts(self):
+        """Number of (device, stream) exchange buffers whose bounded in-kernel wait ever expired (0 = healthy)."""
+        return sum(int(buf[_lib.SYNC_TIMEOUT_WORD].item() != 0) for buf in self._sync.values())
+
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
                         momentum, eps, training, margin=MARGIN, l2=L2):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x.
@@ -247,8 +267,8 @@ class HipKernels:
                 x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
                 _p(running_mean), _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu),
                 y.data_ptr(), base, p_gamma if weight is not None else None, p_beta if weight is not None else None,
-                p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), ws, st),
-                'passport_bn_fwd')
+                p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), ws,
+                self._sync_words(dev, st) if training else None, st), 'passport_bn_fwd')
         table = small[:8 * c].view(c, 8)
         gamma = beta = loss = acc = None
         if weight is not None:
@@ -276,7 +296,7 @@ class HipKernels:
                 dy.data_ptr(), x.data_ptr(), table.data_ptr(), _p(m), _p(b), alpha, margin, l2, _p(dloss),
                 _p(dgamma_extra), _p(dbeta_extra), int(training), n, c, hw,
                 (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c,
-                scratch + nws, scratch, st), 'passport_bn_bwd')
+                scratch + nws, scratch, self._sync_words(dev, st), st), 'passport_bn_bwd')
         return dx, dw, dgb[0], dgb[1]
 
     def add_relu_fwd(self, a, b):

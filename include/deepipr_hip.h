@@ -29,7 +29,7 @@ extern "C" {
 #define DEEPIPR_EINVAL (-1)   /* bad shape / null pointer / misaligned pointer / workspace too small */
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 
-#define DEEPIPR_ABI_VERSION 1
+#define DEEPIPR_ABI_VERSION 2
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -57,9 +57,13 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_BN_AFFINE_BWD 14
 #define DEEPIPR_K_SGD 15
 #define DEEPIPR_K_ADD_RELU 16
-#define DEEPIPR_PROFILE_KERNELS 17
+#define DEEPIPR_K_BN_RES_FWD 17
+#define DEEPIPR_K_BN_RES_BWD 18
+#define DEEPIPR_PROFILE_KERNELS 19
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
+/* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
+int deepipr_profile_read_bytes(int kernel, double *total_bytes);
 
 /* ------------------------------------------------------------------ passport conv -> global pool
  * m[k] = mean over (b, oh, ow) of im2col(key)[b, k, (oh,ow)], k = (ci*kh + r)*kw + q, kept in f64,
@@ -165,19 +169,35 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * beta_in are the learnable scale / bias (passportconv2d_private.py:140-141,162-163), dW is not produced.
  * training == 0 uses the running statistics (eval mode) and backward treats them as constants.
  * running_mean / running_var / num_batches_tracked may be NULL (track_running_stats=False) when training.
- * workspace: deepipr_passport_bn_workspace_bytes(N, C, HW) bytes (forward needs it only when training). */
+ * workspace: deepipr_passport_bn_workspace_bytes(N, C, HW) bytes (forward needs it only when training).
+ *
+ * Register-resident single pass.  When the layer's activations fit in the register file of the device (all of
+ * the CIFAR-shape nets at batch <= 128 per GPU) and HW % 4 == 0, both directions run as ONE kernel that loads
+ * x (backward: dy and x) once, forms the channel sums, and produces y (dx) from registers: 8 / 12 B per element
+ * instead of 12 / 20, one launch instead of three (+ the gamma/beta GEMV, resp. the dW update, for layers with W).
+ * Layers with fewer channels than the device has CUs split every channel over several workgroups, which exchange
+ * their partial sums inside the launch through `sync`: DEEPIPR_SYNC_WORDS 32-bit words that are zero before their
+ * first use, are owned by this library from then on (every call leaves the counters a multiple of 64) and are
+ * not shared by calls that can run concurrently.  That form needs all its workgroups co-resident, so pass
+ * sync == NULL whenever another kernel may occupy CUs of the device at the same time (e.g. a collective on a
+ * second stream); channel-owning layers (C >= CUs) then still take the single pass, the others the 3-launch
+ * form.  word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero if a bounded in-kernel wait ever expired.
+ * deepipr_set_resident(0) disables the single-pass kernels process-wide (testing), (1) restores the default. */
+#define DEEPIPR_SYNC_WORDS (4096 + 16)
+#define DEEPIPR_SYNC_TIMEOUT_WORD 4096
+int deepipr_set_resident(int mode);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
                             const float *beta_in, const float *b, float alpha, float margin, float l2,
                             float *running_mean, float *running_var, long long *num_batches_tracked,
                             float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
                             float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
-                            int8_t *bits, void *workspace, void *stream);
+                            int8_t *bits, void *workspace, unsigned int *sync, void *stream);
 int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table, const double *m, const float *b,
                             float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
-                            void *stream);
+                            unsigned int *sync, void *stream);
 
 /* ------------------------------------------------------------------ optimiser step on flat buffers
  * SGD with momentum and weight decay, torch.optim.SGD semantics (dampening 0, no Nesterov):

@@ -225,16 +225,32 @@ def test_fused_layer_equals_unfused(K, shape, with_sign):
 
 # ----------------------------------------------------------------------------- BatchNorm-fused layer
 BN_SHAPES = [(128, 512, 4, 4, 4608), (64, 384, 8, 8, 1728), (6, 64, 32, 32, 27), (3, 16, 56, 56, 144),
-             (5, 24, 7, 7, 75), (2, 3, 5, 3, 12), (9, 10, 2, 2, 40), (16, 64, 7, 7, 576), (4, 8, 9, 9, 72)]
+             (5, 24, 7, 7, 75), (2, 3, 5, 3, 12), (9, 10, 2, 2, 40), (16, 64, 7, 7, 576), (4, 8, 9, 9, 72),
+             # register-resident single pass: channel split over 4 / 2 workgroups with the in-launch exchange,
+             # ragged last slice, forward-only fit (backward falls back), channel-owning, 2 and 8 channels per group
+             (128, 64, 32, 32, 27), (128, 128, 16, 16, 576), (34, 64, 32, 32, 27), (130, 64, 32, 32, 27),
+             (128, 256, 8, 8, 1152), (32, 512, 4, 4, 4608), (7, 16, 2, 2, 36)]
+
+
+@pytest.fixture(params=['resident', 'two_pass'])
+def bn_path(request):
+    """Both implementations of the BatchNorm-fused layer: the register-resident single pass (taken whenever the
+    shape fits) and the 3-launch form it falls back to."""
+    from deepipr_amd import _lib
+    _lib.set_resident(request.param == 'resident')
+    yield request.param
+    _lib.set_resident(True)
 
 
 @pytest.mark.parametrize('mode', ['passport', 'passport_nosign', 'public', 'eval'])
 @pytest.mark.parametrize('shape', BN_SHAPES)
-def test_passport_bn_fused_fwd_bwd(K, shape, mode):
+def test_passport_bn_fused_fwd_bwd(K, shape, mode, bn_path):
     """deepipr_passport_bn_fwd/_bwd against a float64 ATen-style batch norm + the numpy passport oracle
     (tests/oracle_kernels.py) on the same inputs: y, running statistics, dx, dgamma, dbeta, dW."""
     from tests.oracle_kernels import OracleKernels
     O = OracleKernels()
+    if bn_path == 'two_pass' and shape[0] * shape[1] * shape[2] * shape[3] > (1 << 22) and mode != 'passport':
+        pytest.skip('large shapes: one mode is enough for the fallback path')
     n, c, h, w, kk = shape
     rs = np.random.RandomState(n * 7 + c)
     x = (rs.standard_normal((n, c, h, w)) * 1.7 + 0.3).astype(np.float32)
@@ -294,6 +310,59 @@ def test_passport_bn_fused_fwd_bwd(K, shape, mode):
     if not public:
         ref = b_ref[1].numpy()
         assert np.abs(host(b_gpu[1]) - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6)
+    assert K.sync_timeouts() == 0
+
+
+def test_resident_single_pass_is_deterministic_and_shares_its_exchange_words(K):
+    """The in-launch exchange: layers with different slice counts interleaved on one stream (they share the
+    exchange words, which every call advances by 64), repeated; results are bit-identical run to run and agree
+    with the 3-launch form; no bounded wait ever expired."""
+    from deepipr_amd import _lib
+    shapes = [(128, 64, 32, 32), (128, 128, 16, 16), (64, 32, 32, 32), (128, 256, 8, 8), (33, 64, 16, 16)]
+    rs = np.random.RandomState(3)
+    data = []
+    for n, c, h, w in shapes:
+        data.append((dev(rs.standard_normal((n, c, h, w)) * 1.3 + 0.2), dev(rs.standard_normal((n, c, h, w))),
+                     dev(1 + 0.3 * rs.standard_normal(c)), dev(0.2 * rs.standard_normal(c))))
+
+    def sweep():
+        outs = []
+        for x, dy, g, b in data:
+            c = x.shape[1]
+            rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+            o = K.passport_bn_fwd(x, None, None, g, b, None, 0.0, True, rm, rv, None, 0.1, 1e-5, True)
+            bk = K.passport_bn_bwd(dy, x, o[1], None, None, 0.0, None, None, None, None, True, True)
+            outs.append((o[0], o[1][:, :4].clone(), rm, rv, bk[0], bk[2], bk[3]))
+        return outs
+
+    first = sweep()
+    for _ in range(3):
+        again = sweep()
+        for a, b in zip(first, again):
+            for ta, tb in zip(a, b):
+                assert torch.equal(ta, tb)
+    assert K.sync_timeouts() == 0
+    _lib.set_resident(False)
+    try:
+        ref = sweep()
+    finally:
+        _lib.set_resident(True)
+    for a, b in zip(first, ref):
+        for i, (ta, tb) in enumerate(zip(a, b)):
+            scale = float(tb.abs().max()) + 1e-12
+            diff = (ta - tb).abs()
+            if i in (0, 4):                       # y / dx: isolated ReLU-kink flips allowed
+                assert float((diff > 1e-4 * scale).float().mean()) < 1e-4
+            else:
+                assert float(diff.max()) <= 2e-5 * scale, i
+    # in-situ timing sees one launch per direction on this path
+    _lib.profile_enable(True)
+    sweep()
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    assert prof['bn_res_fwd'][1] == len(shapes) and prof['bn_res_bwd'][1] == len(shapes)
+    assert prof['bn_stats'][1] == 0 and prof['bn_affine_bwd'][1] == 0
 
 
 def test_fused_bn_layer_equals_unfused_layer_in_a_block(K):
@@ -691,6 +760,7 @@ def test_in_situ_profile_counts_launches(K):
     prof = _lib.profile_read()
     assert prof['affine_fwd'][1] == 3 and prof['affine_bwd'][1] == 1 and prof['reduce_partials'][1] == 1
     assert 0.0 < prof['affine_fwd'][0] < 5.0                        # milliseconds for three tiny kernels
+    assert _lib.profile_read_bytes()['affine_fwd'] == 3 * 8.0 * x.numel()
     _lib.profile_enable(1)
     _lib.profile_enable(0)
     assert _lib.profile_read()['affine_fwd'] == (0.0, 0)
