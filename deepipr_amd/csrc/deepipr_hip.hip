@@ -14,10 +14,13 @@
 //     GEMV that streams W exactly once.  Reshaping it into a GEMM to reach MFMA would multiply the
 //     flops by L = Ho*Wo without removing a single byte of W traffic, so no MFMA is used.
 //   * 64-wide wavefronts: cross-lane reductions are __shfl_xor trees over 64 lanes, per-workgroup
-//     combines go through LDS, cross-workgroup combines are fixed-order partial sums finished in the
-//     prologue of the NEXT kernel (no float atomics, no in-launch grid sync): bit-reproducible.
-//   * 16 B per lane (float4) global accesses wherever the plane size allows; grids are sized to
-//     >= 4 workgroups per CU (256 CUs) and capped at 2048 with grid-stride loops.
+//     combines go through LDS, cross-workgroup combines are fixed-order partial sums (no float atomics):
+//     bit-reproducible.  They are finished in the prologue of the NEXT kernel, except in the
+//     register-resident single-pass kernels (k_bn_res_*), where the few workgroups of one channel exchange
+//     two doubles inside the launch (write-through stores + a relaxed agent-scope ticket, bounded wait).
+//   * 16 B per lane (float4) global accesses wherever the plane size allows; streaming grids are sized to
+//     >= 4 workgroups per CU (256 CUs) and capped at 2048 with grid-stride loops; the resident kernels use
+//     one 1024-thread workgroup per CU and keep the layer's activations in the 128 MB register file.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
