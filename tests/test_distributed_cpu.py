@@ -77,6 +77,8 @@ def _worker(rank, world, port, private, out_dir, flat=False):
         wrapped = D.replicate(DualBranch(model) if private else model, dev)
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
         opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    # with a gradient exchange sharing the device, the co-residency-dependent single-pass kernels are switched off
+    assert passport_ops.kernels.allow_sync is False
     x, y = _batch()
     lo, hi = rank * 4, rank * 4 + 4
     step = train_step_v23 if private else train_step_v1

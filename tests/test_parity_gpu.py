@@ -793,7 +793,9 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
     from deepipr_amd.experiments.graph_step import GraphedTrainStep
     from deepipr_amd.experiments.trainer import train_step_v1
     from deepipr_amd.flat_sgd import FlatSGD
+    from deepipr_amd import passport_ops
     monkeypatch.setenv('DEEPIPR_FORCE_DDP', '1')
+    monkeypatch.setattr(passport_ops.kernels, 'allow_sync', True)      # FlatSGD clears it; restored afterwards
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1)
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
