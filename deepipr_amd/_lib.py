@@ -53,6 +53,13 @@ SIGNATURES = {
     'deepipr_passport_bn_bwd': (_int, [_f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _f32p,
                                        _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _vp,
                                        _vp, _vp]),
+    'deepipr_passport_gn_supported': (_int, [_int, _int, _int, _int]),
+    'deepipr_passport_gn_workspace_bytes': (_sz, [_int, _int, _int]),
+    'deepipr_passport_gn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _flt, _int,
+                                       _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i8p, _vp]),
+    'deepipr_passport_gn_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p,
+                                       _f32p, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp,
+                                       _vp]),
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
@@ -104,7 +111,7 @@ def check(rc, what):
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
-                   'bn_res_bwd']
+                   'bn_res_bwd', 'gn_fwd', 'gn_bwd']
 
 
 def set_resident(on):

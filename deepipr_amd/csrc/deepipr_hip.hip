@@ -1575,6 +1575,195 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
 }
 
 // ============================================================================================
+// GroupNorm / InstanceNorm (affine=False, models/layers/passportconv2d.py:59-62: GroupNorm(o // 16, o),
+// InstanceNorm2d(o)) fused with the passport affine + ReLU, register-resident like k_bn_res_*.
+//
+// The statistics of these norms live on one (sample, group) chunk = cpg adjacent channels of one sample =
+// U = cpg*HW/4 contiguous float4 -- no cross-workgroup dependency at all.  A thread group of TG lanes
+// (a power of two: part of a wavefront for small chunks, up to 1024 threads for 64 KB chunks) owns one chunk,
+// loads it once (F4 float4 per lane), forms mean / invstd, and writes y from registers: 8 B/element.
+// Backward, same ownership: dz (ReLU mask recomputed), gz = gamma*dz and xhat stay in registers,
+//   dx = invstd * (gz - mean_chunk(gz) - xhat * mean_chunk(gz*xhat))                          12 B/element,
+// and the per-channel sums of dz*xhat and dz (dgamma / dbeta before the batch reduction) go through LDS in unit
+// order to part[n][2][C]; k_passport_bwd_finish then reduces over n in fixed order and writes dgamma, dbeta, dW.
+// ============================================================================================
+struct GnPlan {
+    int F4, TG, T;        // float4 units per lane, lanes per chunk (power of two), threads per workgroup
+    int U, q4, cpg;       // float4 units per chunk, per plane; channels per group
+    int groups, chunks;   // groups per sample, N * groups
+    FastDiv q4div;
+};
+
+// Sum of (a, b) over the TG lanes of this thread's chunk; every lane of the chunk gets the result.
+// red: 2 * 16 doubles of LDS (used when TG > 64).
+__device__ __forceinline__ void gn_group_sums(double &a, double &b, int TG, double *red) {
+    const int lim = TG < kWave ? TG : kWave;
+    for (int off = lim >> 1; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, kWave);
+        b += __shfl_xor(b, off, kWave);
+    }
+    if (TG > kWave) {                              // uniform over the launch
+        const int wave = threadIdx.x >> 6, wpg = TG >> 6, g0 = (wave / wpg) * wpg;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            red[wave * 2 + 0] = a;
+            red[wave * 2 + 1] = b;
+        }
+        __syncthreads();
+        a = 0.0;
+        b = 0.0;
+        for (int w = 0; w < wpg; ++w) {
+            a += red[(g0 + w) * 2 + 0];
+            b += red[(g0 + w) * 2 + 1];
+        }
+    }
+}
+
+template <int F4>
+__global__ void k_gn_fwd(const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
+                         const float *__restrict__ beta, float *__restrict__ stats, int relu, GnPlan pl, float eps) {
+    __shared__ double red[32];
+    const int t = threadIdx.x;
+    const int chunk = blockIdx.x * (pl.T / pl.TG) + t / pl.TG;
+    const int lane = t & (pl.TG - 1);
+    const bool on = chunk < pl.chunks;
+    const size_t base = static_cast<size_t>(on ? chunk : 0) * pl.U;
+    float4 v[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int u = lane + k * pl.TG;
+        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (on && u < pl.U) v[k] = x[base + u];
+    }
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        a0 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        a1 = fmaf(v[k].x, v[k].x, a1);
+        a1 = fmaf(v[k].y, v[k].y, a1);
+        a1 = fmaf(v[k].z, v[k].z, a1);
+        a1 = fmaf(v[k].w, v[k].w, a1);
+    }
+    double s1 = static_cast<double>(a0), s2 = static_cast<double>(a1);
+    gn_group_sums(s1, s2, pl.TG, red);
+    const double inv_m = 1.0 / (static_cast<double>(pl.U) * 4.0);
+    const double mu = s1 * inv_m;
+    double var = s2 * inv_m - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mean = static_cast<float>(mu);
+    const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (on && lane == 0) *reinterpret_cast<float2 *>(stats + static_cast<size_t>(chunk) * 2) = make_float2(mean, invstd);
+    const int c0 = (on ? chunk % pl.groups : 0) * pl.cpg;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int u = lane + k * pl.TG;
+        if (on && u < pl.U) {
+            const int c = c0 + static_cast<int>(fdiv(static_cast<unsigned>(u), pl.q4div));
+            const float4 ch = make_float4(mean, invstd, gamma ? gamma[c] : 1.0f, beta ? beta[c] : 0.0f);
+            float4 o;
+            if (relu)
+                o = make_float4(bn_affine1<true>(v[k].x, ch), bn_affine1<true>(v[k].y, ch),
+                                bn_affine1<true>(v[k].z, ch), bn_affine1<true>(v[k].w, ch));
+            else
+                o = make_float4(bn_affine1<false>(v[k].x, ch), bn_affine1<false>(v[k].y, ch),
+                                bn_affine1<false>(v[k].z, ch), bn_affine1<false>(v[k].w, ch));
+            y[base + u] = o;
+        }
+    }
+}
+
+template <int F4>
+__global__ void k_gn_bwd(const float4 *__restrict__ dy, const float4 *__restrict__ x,
+                         const float *__restrict__ stats, const float *__restrict__ gamma,
+                         const float *__restrict__ beta, float4 *__restrict__ dx, double *__restrict__ part, int relu,
+                         int C, GnPlan pl) {
+    extern __shared__ __attribute__((aligned(16))) float unit_sums[];      // [chunks per workgroup][U][2]
+    __shared__ double red[32];
+    const int t = threadIdx.x;
+    const int cpb = pl.T / pl.TG;
+    const int slot = t / pl.TG;
+    const int chunk = blockIdx.x * cpb + slot;
+    const int lane = t & (pl.TG - 1);
+    const bool on = chunk < pl.chunks;
+    const size_t base = static_cast<size_t>(on ? chunk : 0) * pl.U;
+    const int c0 = (on ? chunk % pl.groups : 0) * pl.cpg;
+    float2 st = make_float2(0.0f, 1.0f);
+    if (on) st = *reinterpret_cast<const float2 *>(stats + static_cast<size_t>(chunk) * 2);
+    float4 gz[F4], xh[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int u = lane + k * pl.TG;
+        gz[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        xh[k] = make_float4(st.x, st.x, st.x, st.x);
+        if (on && u < pl.U) {
+            gz[k] = dy[base + u];
+            xh[k] = x[base + u];
+        }
+    }
+    float a0 = 0.0f, a1 = 0.0f;
+    float *mine = unit_sums + static_cast<size_t>(slot) * pl.U * 2;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int u = lane + k * pl.TG;
+        const int c = c0 + ((on && u < pl.U) ? static_cast<int>(fdiv(static_cast<unsigned>(u), pl.q4div)) : 0);
+        const float4 ch = make_float4(st.x, st.y, gamma ? gamma[c] : 1.0f, beta ? beta[c] : 0.0f);
+        const float4 d = gz[k], v = xh[k];
+        float4 dz;
+        res_bwd_prep(d.x, v.x, ch, relu, dz.x, xh[k].x);
+        res_bwd_prep(d.y, v.y, ch, relu, dz.y, xh[k].y);
+        res_bwd_prep(d.z, v.z, ch, relu, dz.z, xh[k].z);
+        res_bwd_prep(d.w, v.w, ch, relu, dz.w, xh[k].w);
+        if (on && u < pl.U) {                       // this unit's share of its channel's dgamma / dbeta
+            float p0 = dz.x * xh[k].x;
+            p0 = fmaf(dz.y, xh[k].y, p0);
+            p0 = fmaf(dz.z, xh[k].z, p0);
+            p0 = fmaf(dz.w, xh[k].w, p0);
+            *reinterpret_cast<float2 *>(mine + static_cast<size_t>(u) * 2) =
+                make_float2(p0, (dz.x + dz.y) + (dz.z + dz.w));
+        }
+        gz[k] = make_float4(ch.z * dz.x, ch.z * dz.y, ch.z * dz.z, ch.z * dz.w);
+        a0 = fmaf(gz[k].x, xh[k].x, a0);
+        a0 = fmaf(gz[k].y, xh[k].y, a0);
+        a0 = fmaf(gz[k].z, xh[k].z, a0);
+        a0 = fmaf(gz[k].w, xh[k].w, a0);
+        a1 += (gz[k].x + gz[k].y) + (gz[k].z + gz[k].w);
+    }
+    double s2 = static_cast<double>(a0), s1 = static_cast<double>(a1);
+    gn_group_sums(s2, s1, pl.TG, red);
+    const double inv_m = 1.0 / (static_cast<double>(pl.U) * 4.0);
+    const float c2 = static_cast<float>(s1 * inv_m), c3 = static_cast<float>(s2 * inv_m);
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int u = lane + k * pl.TG;
+        if (on && u < pl.U)
+            dx[base + u] = make_float4(st.y * (gz[k].x - c2 - xh[k].x * c3), st.y * (gz[k].y - c2 - xh[k].y * c3),
+                                       st.y * (gz[k].z - c2 - xh[k].z * c3), st.y * (gz[k].w - c2 - xh[k].w * c3));
+    }
+    // per-channel sums of this workgroup's chunks, one wavefront per (chunk, channel), in unit order
+    __syncthreads();
+    const int wave = t >> 6, wl = t & 63, nw = pl.T >> 6;
+    for (int job = wave; job < cpb * pl.cpg; job += nw) {
+        const int sl = job / pl.cpg, cc = job - sl * pl.cpg;
+        const int ck = blockIdx.x * cpb + sl;
+        if (ck >= pl.chunks) continue;                       // uniform per wavefront
+        const float *p = unit_sums + (static_cast<size_t>(sl) * pl.U + static_cast<size_t>(cc) * pl.q4) * 2;
+        double g = 0.0, b = 0.0;
+        for (int e = wl; e < pl.q4; e += kWave) {
+            const float2 q = *reinterpret_cast<const float2 *>(p + static_cast<size_t>(e) * 2);
+            g += static_cast<double>(q.x);
+            b += static_cast<double>(q.y);
+        }
+        g = wave_sum(g);
+        b = wave_sum(b);
+        if (wl == 0) {
+            const int n = ck / pl.groups, c = (ck - n * pl.groups) * pl.cpg + cc;
+            part[(static_cast<size_t>(n) * 2 + 0) * C + c] = g;
+            part[(static_cast<size_t>(n) * 2 + 1) * C + c] = b;
+        }
+    }
+}
+
+// ============================================================================================
 // SGD with momentum and weight decay over one flat parameter buffer (experiments/classification.py:47-50:
 // optim.SGD(lr, momentum=0.9, weight_decay=1e-4); torch semantics: g += wd*p; buf = mu*buf + g; p -= lr*buf).
 // One streaming pass: reads p, g, buf and writes p, buf = 20 B per parameter.  `grad_scale` folds the
@@ -1737,6 +1926,25 @@ size_t bwd_workspace_bytes(int N, int C, int HW) {
     const BwdPlan a = plan_bwd(N, C, HW, true), b = plan_bwd(N, C, HW, false);
     const int ns = a.NS > b.NS ? a.NS : b.NS;
     return static_cast<size_t>(ns) * 2 * C * sizeof(double);
+}
+
+int launch_passport_finish(const double *part, int NS, int C, const float *gamma, const float *b, float alpha,
+                           float margin, float l2, const float *dloss, const float *dgamma_extra,
+                           const float *dbeta_extra, const double *s, int K, float *dgamma, float *dbeta, float *dW,
+                           hipStream_t st) {
+    ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
+    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
+#define DEEPIPR_FINISH_ARGS part, NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW
+    if (C >= 2 * kRowPairMinCo) {
+        const dim3 grid((C + 1) / 2);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+    } else {
+        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
+    }
+#undef DEEPIPR_FINISH_ARGS
+    return check_launch("passport_bwd(finish)");
 }
 
 bool bad_dims(int N, int C, int HW) { return N <= 0 || C <= 0 || HW <= 0; }
@@ -1952,19 +2160,8 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
     double *part = static_cast<double *>(workspace);
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
-    ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
-    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
-#define DEEPIPR_FINISH_ARGS part, pl.NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW
-    if (C >= 2 * kRowPairMinCo) {
-        const dim3 grid((C + 1) / 2);
-        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
-        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 2>), grid, dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
-    } else {
-        if (vec) DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<true, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
-        else DEEPIPR_LAUNCH(prof, (k_passport_bwd_finish<false, 1>), dim3(C), dim3(kThreads), st, DEEPIPR_FINISH_ARGS);
-    }
-#undef DEEPIPR_FINISH_ARGS
-    return check_launch("passport_bwd(finish)");
+    return launch_passport_finish(part, pl.NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K,
+                                  dgamma, dbeta, dW, st);
 }
 
 }  // extern "C"
@@ -2112,6 +2309,37 @@ int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx,
     }
     return check_launch("passport_bn_bwd(resident)");
 }
+
+
+// ---- GroupNorm / InstanceNorm fused layer: planning and launch ----
+bool plan_gn(int N, int C, int P, int groups, GnPlan *out) {
+    if (groups <= 0 || C % groups != 0 || P % 4 != 0) return false;
+    GnPlan pl{};
+    pl.cpg = C / groups;
+    pl.q4 = P / 4;
+    const long long U = static_cast<long long>(pl.cpg) * pl.q4;
+    if (U > 6144) return false;                    // registers (F4 <= 8 at 1024 lanes) and 48 KB of LDS in backward
+    pl.U = static_cast<int>(U);
+    int tg = 1;
+    while (tg < pl.U && tg < 1024) tg <<= 1;
+    pl.TG = tg;
+    const int need = (pl.U + tg - 1) / tg;
+    pl.F4 = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    pl.T = tg < kThreads ? kThreads : tg;
+    pl.groups = groups;
+    pl.chunks = N * groups;
+    pl.q4div = make_fastdiv(static_cast<unsigned>(pl.q4));
+    *out = pl;
+    return true;
+}
+
+#define DEEPIPR_GN_CASES(KERNEL, LDS, ...)                                                                          \
+    switch (pl.F4) {                                                                                               \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(pl.T), LDS, st, __VA_ARGS__); break;                     \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(pl.T), LDS, st, __VA_ARGS__); break;                     \
+        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(pl.T), LDS, st, __VA_ARGS__); break;                     \
+        default: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(pl.T), LDS, st, __VA_ARGS__); break;                    \
+    }
 
 }  // namespace
 
@@ -2321,6 +2549,107 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                                static_cast<unsigned>(total), pdiv, cdiv, static_cast<unsigned>(C));
     }
     return check_launch("passport_bn_bwd(apply)");
+}
+
+
+int deepipr_passport_gn_supported(int N, int C, int HW, int groups) {
+    GnPlan pl;
+    return (!bad_dims(N, C, HW) && plan_gn(N, C, HW, groups, &pl)) ? 1 : 0;
+}
+
+size_t deepipr_passport_gn_workspace_bytes(int N, int C, int HW) {
+    if (bad_dims(N, C, HW)) return 0;
+    return static_cast<size_t>(N) * 2 * C * sizeof(double);
+}
+
+int deepipr_passport_gn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
+                            const float *beta_in, const float *b, float alpha, float margin, float l2, int groups,
+                            float eps, int N, int C, int HW, int K, int relu, float *y, float *stats, float *gamma,
+                            float *beta, float *loss, float *acc, int8_t *bits, void *stream) {
+    if (!x || !y || !stats || bad_dims(N, C, HW)) return fail(DEEPIPR_EINVAL, "passport_gn_fwd: bad argument");
+    if (W && (!m || !gamma || !beta || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_gn_fwd: W needs m, gamma, beta, K");
+    if (loss && (!b || !acc)) return fail(DEEPIPR_EINVAL, "passport_gn_fwd: sign loss needs b and acc");
+    if (loss && !W && !gamma_in) return fail(DEEPIPR_EINVAL, "passport_gn_fwd: sign loss needs a gamma");
+    GnPlan pl;
+    if (!aligned16(x) || !aligned16(y) || !plan_gn(N, C, HW, groups, &pl))
+        return fail(DEEPIPR_EUNSUPPORTED, "passport_gn_fwd: group of %d channels x %d does not fit the fused form",
+                    groups > 0 ? C / groups : 0, HW);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *g = gamma_in, *bt = beta_in;
+    if (W) {
+        int rc = deepipr_gamma_beta_fwd(W, m, C, K, gamma, beta, stream);
+        if (rc != DEEPIPR_OK) return rc;
+        g = gamma;
+        bt = beta;
+    }
+    {
+        ProfScope prof(DEEPIPR_K_GN_FWD, st);
+        prof.bytes = 8.0 * static_cast<double>(N) * C * HW;
+        const dim3 grid((pl.chunks + pl.T / pl.TG - 1) / (pl.T / pl.TG));
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        float4 *y4 = reinterpret_cast<float4 *>(y);
+        if (prof.a) {
+            prof.used = true;
+            switch (pl.F4) {
+                case 1: hipExtLaunchKernelGGL((k_gn_fwd<1>), grid, dim3(pl.T), 0, st, prof.a, prof.b, 0, x4, y4, g, bt, stats, relu, pl, eps); break;
+                case 2: hipExtLaunchKernelGGL((k_gn_fwd<2>), grid, dim3(pl.T), 0, st, prof.a, prof.b, 0, x4, y4, g, bt, stats, relu, pl, eps); break;
+                case 4: hipExtLaunchKernelGGL((k_gn_fwd<4>), grid, dim3(pl.T), 0, st, prof.a, prof.b, 0, x4, y4, g, bt, stats, relu, pl, eps); break;
+                default: hipExtLaunchKernelGGL((k_gn_fwd<8>), grid, dim3(pl.T), 0, st, prof.a, prof.b, 0, x4, y4, g, bt, stats, relu, pl, eps); break;
+            }
+        } else {
+            DEEPIPR_GN_CASES(k_gn_fwd, 0, x4, y4, g, bt, stats, relu, pl, eps)
+        }
+        int rc = check_launch("passport_gn_fwd");
+        if (rc != DEEPIPR_OK) return rc;
+    }
+    if (loss) return deepipr_sign_loss_fwd(g, b, alpha, margin, l2, C, loss, acc, bits, stream);
+    return DEEPIPR_OK;
+}
+
+int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats, const float *gamma,
+                            const float *beta, const double *m, const float *b, float alpha, float margin, float l2,
+                            const float *dloss, const float *dgamma_extra, const float *dbeta_extra, int groups,
+                            int N, int C, int HW, int K, int relu, float *dx, float *dW, float *dgamma, float *dbeta,
+                            void *workspace, void *stream) {
+    if (!dy || !x || !stats || !dx || !dgamma || !dbeta || !workspace || bad_dims(N, C, HW))
+        return fail(DEEPIPR_EINVAL, "passport_gn_bwd: bad argument");
+    if (dW && (!m || !gamma || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_gn_bwd: dW needs m, gamma and K");
+    if (dloss && (!b || !gamma)) return fail(DEEPIPR_EINVAL, "passport_gn_bwd: sign loss needs b and gamma");
+    GnPlan pl;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !plan_gn(N, C, HW, groups, &pl))
+        return fail(DEEPIPR_EUNSUPPORTED, "passport_gn_bwd: group does not fit the fused form");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *part = static_cast<double *>(workspace);
+    {
+        ProfScope prof(DEEPIPR_K_GN_BWD, st);
+        prof.bytes = 12.0 * static_cast<double>(N) * C * HW;
+        const int cpb = pl.T / pl.TG;
+        const dim3 grid((pl.chunks + cpb - 1) / cpb);
+        const size_t lds = static_cast<size_t>(cpb) * pl.U * 2 * sizeof(float);
+        const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
+        float4 *o4 = reinterpret_cast<float4 *>(dx);
+        if (prof.a) {
+            prof.used = true;
+            switch (pl.F4) {
+                case 1: hipExtLaunchKernelGGL((k_gn_bwd<1>), grid, dim3(pl.T), lds, st, prof.a, prof.b, 0, d4, x4, stats, gamma, beta, o4, part, relu, C, pl); break;
+                case 2: hipExtLaunchKernelGGL((k_gn_bwd<2>), grid, dim3(pl.T), lds, st, prof.a, prof.b, 0, d4, x4, stats, gamma, beta, o4, part, relu, C, pl); break;
+                case 4: hipExtLaunchKernelGGL((k_gn_bwd<4>), grid, dim3(pl.T), lds, st, prof.a, prof.b, 0, d4, x4, stats, gamma, beta, o4, part, relu, C, pl); break;
+                default: hipExtLaunchKernelGGL((k_gn_bwd<8>), grid, dim3(pl.T), lds, st, prof.a, prof.b, 0, d4, x4, stats, gamma, beta, o4, part, relu, C, pl); break;
+            }
+        } else {
+            DEEPIPR_GN_CASES(k_gn_bwd, lds, d4, x4, stats, gamma, beta, o4, part, relu, C, pl)
+        }
+        int rc = check_launch("passport_gn_bwd");
+        if (rc != DEEPIPR_OK) return rc;
+    }
+    if (!dW) {
+        ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
+        DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), st, part, N, C,
+                       dgamma, dbeta);
+        return check_launch("passport_gn_bwd(finish)");
+    }
+    return launch_passport_finish(part, N, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, m, K,
+                                  dgamma, dbeta, dW, st);
 }
 
 

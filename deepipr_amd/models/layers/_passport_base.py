@@ -216,6 +216,19 @@ class PassportLayerBase(nn.Module):
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
             return y
+        if self.fuse_norm and self.bn is not None and p_scale == p_bias and P.gn_is_fusable(self.bn, x) \
+                and not getattr(self.bn, 'affine', False):
+            # GroupNorm / InstanceNorm folded in: one register-resident kernel per direction (deepipr_passport_gn_*)
+            if p_scale:
+                return P.gn_affine_relu(x, self.scale, self.bias, self.bn, relu)
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
+                x, self.weight, skey, key, self.b if sl is not None else None, m, self.bn, self.alpha, relu,
+                stride, pad)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
         x = self.bn(x)
         if p_scale and p_bias:                       # public branch: learnable affine, no sign loss
             return P.affine_relu(x, self.scale, self.bias, relu)

@@ -2,8 +2,10 @@
 models/layers/conv2d.py:5-36).  The convolution stays on the vendor library (MIOpen).  BatchNorm2d(affine) +
 ReLU is arithmetically the passport layer's public branch -- relu(weight * xhat + bias) with learnable
 weight / bias -- so on the GPU it runs through the same fused kernels (deepipr_passport_bn_fwd/_bwd, W-less
-form): 6 streaming launches and 32 B per element instead of MIOpen batch-norm + clamp + threshold_backward +
-batch-norm backward at ~48 B per element.  `fuse_norm = False` restores the library ops."""
+form): one register-resident launch per direction at 8 / 12 B per element (three streaming launches when the
+activation does not fit) instead of MIOpen batch-norm + clamp + threshold_backward + batch-norm backward at
+~48 B per element.  GroupNorm(affine) / InstanceNorm2d + ReLU likewise through deepipr_passport_gn_*.
+`fuse_norm = False` restores the library ops."""
 import os
 
 import torch
@@ -45,6 +47,11 @@ class ConvBlock(nn.Module):
                 and self.bn.affine and self.bn.momentum is not None and x.dtype == torch.float32):
             from deepipr_amd import passport_ops as P
             return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None)
+        if self.fuse_norm and isinstance(self.bn, (nn.GroupNorm, nn.InstanceNorm2d)) and x.is_cuda:
+            from deepipr_amd import passport_ops as P
+            if P.gn_is_fusable(self.bn, x):          # GroupNorm(affine) / InstanceNorm2d + ReLU in one kernel
+                return P.gn_affine_relu(x, getattr(self.bn, 'weight', None), getattr(self.bn, 'bias', None), self.bn,
+                                        self.relu is not None)
         if self.bn is not None:
             x = self.bn(x)
         if self.relu is not None:

@@ -299,6 +299,66 @@ class HipKernels:
                 scratch + nws, scratch, self._sync_words(dev, st), st), 'passport_bn_bwd')
         return dx, dw, dgb[0], dgb[1]
 
+    # ---- GroupNorm / InstanceNorm-fused layer (include/deepipr_hip.h: deepipr_passport_gn_*) ----
+    _gn_ok = {}
+
+    def gn_supported(self, n, c, hw, groups):
+        key = (n, c, hw, groups)
+        v = self._gn_ok.get(key)
+        if v is None:
+            v = self._gn_ok[key] = bool(_lib.lib().deepipr_passport_gn_supported(n, c, hw, groups))
+        return v
+
+    def passport_gn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, groups, eps, margin=MARGIN, l2=L2):
+        """GroupNorm(groups, affine=False) + affine + ReLU (+ sign loss) from the conv output x.
+        -> y, stats[N*groups,2], gamma, beta, loss, acc, bits (gamma/beta None on the W-less branch)."""
+        dev = _chk(x, weight)
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        st = _stream(dev)
+        y = torch.empty_like(x)
+        small = torch.empty(2 * n * groups + 2 * c + 2, dtype=torch.float32, device=dev)
+        base = small.data_ptr()
+        p_gamma = base + 8 * n * groups
+        p_beta, p_loss = p_gamma + 4 * c, p_gamma + 8 * c
+        bits = torch.empty(c, dtype=torch.int8, device=dev) if b is not None else None
+        k = weight.numel() // c if weight is not None else 0
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_passport_gn_fwd(
+                x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2, groups, eps,
+                n, c, hw, k, int(relu), y.data_ptr(), base, p_gamma if weight is not None else None,
+                p_beta if weight is not None else None, p_loss if b is not None else None,
+                (p_loss + 4) if b is not None else None, _p(bits), st), 'passport_gn_fwd')
+        stats = small[:2 * n * groups].view(n * groups, 2)
+        gamma = beta = loss = acc = None
+        if weight is not None:
+            o = 2 * n * groups
+            gamma, beta = small[o:o + c], small[o + c:o + 2 * c]
+        if b is not None:
+            o = 2 * n * groups + 2 * c
+            loss, acc = small[o], small[o + 1]
+        return y, stats, gamma, beta, loss, acc, bits
+
+    def passport_gn_bwd(self, dy, x, stats, gamma, beta, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu,
+                        groups, margin=MARGIN, l2=L2):
+        """-> dx, dW (None when wshape is None), dgamma, dbeta."""
+        dev = _chk(dy, x)
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        st = _stream(dev)
+        ws = self._scratch(dev, st, n * 2 * c * 8)
+        dx = torch.empty_like(x)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        pg = dgb.data_ptr()
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_passport_gn_bwd(
+                dy.data_ptr(), x.data_ptr(), stats.data_ptr(), _p(gamma), _p(beta), _p(m), _p(b), alpha, margin, l2,
+                _p(dloss), _p(dgamma_extra), _p(dbeta_extra), groups, n, c, hw,
+                (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c, ws, st),
+                'passport_gn_bwd')
+        return dx, dw, dgb[0], dgb[1]
+
     def add_relu_fwd(self, a, b):
         dev = _chk(a, b)
         out = torch.empty_like(a)
@@ -541,6 +601,85 @@ def _bn_uses_batch_stats(bn):
 def bn_is_fusable(bn):
     """nn.BatchNorm2d without affine parameters and with the default exponential running average."""
     return (isinstance(bn, torch.nn.BatchNorm2d) and not bn.affine and bn.momentum is not None)
+
+
+class _PassportGNLayer(torch.autograd.Function):
+    """GroupNorm / InstanceNorm (affine=False) + passport affine + ReLU + sign loss, fused (deepipr_passport_gn_*):
+    one register-resident kernel per direction (+ the gamma/beta GEMV and the dgamma/dbeta/dW finish).  With
+    weight=None it is the W-less branch: learnable gamma_in / beta_in (public branch, or a ConvBlock's affine
+    norm), either of which may be None (InstanceNorm2d without affine)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, cfg):
+        alpha, relu, stride, pad, groups, eps = cfg
+        x = x.contiguous()
+        w = None if weight is None else weight.contiguous()
+        gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
+        bi = None if beta_in is None else beta_in.contiguous().view(-1)
+        bb = None if b is None else b.contiguous().view(-1)
+        y, stats, gamma, beta, loss, acc, bits = kernels.passport_gn_fwd(x, w, m, gi, bi, bb, float(alpha), relu,
+                                                                         int(groups), float(eps))
+        used_g, used_b = (gamma, beta) if w is not None else (gi, bi)
+        ctx.save_for_backward(x, w, stats, used_g, used_b, m, bb)
+        ctx.cfg = (float(alpha), relu, stride, pad, int(groups), None if key is None else tuple(key.shape))
+        ctx.set_materialize_grads(False)
+        if gamma is None:
+            gamma = beta = x.new_empty(0)
+        if loss is None:
+            loss = acc = x.new_empty(0)
+            bits = torch.empty(0, dtype=torch.int8, device=x.device)
+        ctx.mark_non_differentiable(acc, bits)
+        return y, gamma, beta, loss, acc, bits
+
+    @staticmethod
+    def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
+        x, w, stats, g, bt, m, bb = ctx.saved_tensors
+        alpha, relu, stride, pad, groups, key_shape = ctx.cfg
+        if dy is None:
+            dy = torch.zeros_like(x)
+        dl = None if (bb is None or dloss is None) else dloss.contiguous()
+        if w is None:
+            dgamma_extra = dbeta_extra = None
+        dx, dw, dg, db = kernels.passport_gn_bwd(dy.contiguous(), x, stats, g, bt, m, bb, alpha, dl,
+                                                 _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
+                                                 None if w is None else w.shape, relu, groups)
+        dsk = dk = None
+        if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
+        return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
+                dg if (w is None and ctx.needs_input_grad[4]) else None,
+                db if (w is None and ctx.needs_input_grad[5]) else None, None, None, None)
+
+
+def norm_groups(norm):
+    """Groups of a norm that deepipr_passport_gn_* can fold in: nn.GroupNorm -> num_groups; nn.InstanceNorm2d on
+    instance statistics -> one group per channel; anything else -> 0."""
+    if isinstance(norm, torch.nn.GroupNorm):
+        return norm.num_groups
+    if isinstance(norm, torch.nn.InstanceNorm2d) and not norm.track_running_stats:
+        return norm.num_features
+    return 0
+
+
+def gn_is_fusable(norm, x):
+    """GroupNorm / InstanceNorm2d whose (sample, group) chunk of x fits the register-resident kernels."""
+    groups = norm_groups(norm)
+    if not groups or x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    n, c = x.shape[0], x.shape[1]
+    return kernels.gn_supported(n, c, x.numel() // (n * c), groups)
+
+
+def passport_gn_layer(x, weight, skey, key, b, m, norm, alpha, relu, stride, pad):
+    """Fused passport branch on the conv output `x`; `norm` is the layer's GroupNorm / InstanceNorm2d (affine=False)."""
+    cfg = (alpha, bool(relu), stride, pad, norm_groups(norm), norm.eps)
+    return _PassportGNLayer.apply(x, weight, skey, key, None, None, b, m, cfg)
+
+
+def gn_affine_relu(x, gamma, beta, norm, relu=True):
+    """Fused W-less branch: GroupNorm / InstanceNorm2d + per-channel gamma/beta (None = 1 / 0) + ReLU."""
+    cfg = (0.0, bool(relu), 1, 0, norm_groups(norm), norm.eps)
+    return _PassportGNLayer.apply(x, None, None, None, gamma, beta, None, None, cfg)[0]
 
 
 class _AddReLU(torch.autograd.Function):

@@ -28,6 +28,7 @@ extern "C" {
 #define DEEPIPR_OK 0
 #define DEEPIPR_EINVAL (-1)   /* bad shape / null pointer / misaligned pointer / workspace too small */
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+#define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
 #define DEEPIPR_ABI_VERSION 2
 
@@ -59,7 +60,9 @@ const char *deepipr_last_error(void);
 #define DEEPIPR_K_ADD_RELU 16
 #define DEEPIPR_K_BN_RES_FWD 17
 #define DEEPIPR_K_BN_RES_BWD 18
-#define DEEPIPR_PROFILE_KERNELS 19
+#define DEEPIPR_K_GN_FWD 19
+#define DEEPIPR_K_GN_BWD 20
+#define DEEPIPR_PROFILE_KERNELS 21
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -198,6 +201,35 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
                             unsigned int *sync, void *stream);
+
+/* ------------------------------------------------------------------ GroupNorm / InstanceNorm-fused passport layer
+ * The passport layer's other norms are GroupNorm(o // 16, o, affine=False) and InstanceNorm2d(o)
+ * (passportconv2d.py:59-62; InstanceNorm = one group per channel).  Their statistics live on one (sample, group)
+ * chunk of cpg = C / groups adjacent channels, so norm + passport affine + ReLU is a single register-resident
+ * kernel per direction with no cross-workgroup dependency: forward reads x and writes y (8 B/element), backward
+ * reads dy and x and writes dx (12 B/element) plus per-sample partial sums of dgamma / dbeta that the finish
+ * launch reduces over the batch in fixed order (and turns into dW for layers with W).
+ *   forward : [gamma/beta GEMV when W]  ->  k_gn_fwd  ->  [sign loss]
+ *   backward: k_gn_bwd  ->  finish (dgamma, dbeta[, dW])
+ * replaces: self.bn(x) for norm_type 'gn' / 'in' (native_group_norm / instance_norm and their backward) and
+ *           everything deepipr_passport_fwd / _bwd replace.
+ * stats: [N * groups][2] floats {mean, invstd}, the only state backward needs besides x, gamma, beta.
+ * gamma_in / beta_in (W == NULL): learnable scale / bias of the public branch, or the norm's own affine weights
+ * of a plain ConvBlock; both may be NULL (= 1 and 0: InstanceNorm2d without affine).  Backward takes the gamma /
+ * beta actually used (NULL likewise).  Needs HW % 4 == 0 and cpg * HW <= 24576 floats: ask
+ * deepipr_passport_gn_supported() first; the entry points return DEEPIPR_EUNSUPPORTED without enqueuing anything
+ * otherwise.  workspace (backward): deepipr_passport_gn_workspace_bytes(N, C, HW) bytes. */
+int deepipr_passport_gn_supported(int N, int C, int HW, int groups);
+size_t deepipr_passport_gn_workspace_bytes(int N, int C, int HW);
+int deepipr_passport_gn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
+                            const float *beta_in, const float *b, float alpha, float margin, float l2, int groups,
+                            float eps, int N, int C, int HW, int K, int relu, float *y, float *stats, float *gamma,
+                            float *beta, float *loss, float *acc, int8_t *bits, void *stream);
+int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats, const float *gamma,
+                            const float *beta, const double *m, const float *b, float alpha, float margin, float l2,
+                            const float *dloss, const float *dgamma_extra, const float *dbeta_extra, int groups,
+                            int N, int C, int HW, int K, int relu, float *dx, float *dW, float *dgamma, float *dbeta,
+                            void *workspace, void *stream);
 
 /* ------------------------------------------------------------------ optimiser step on flat buffers
  * SGD with momentum and weight decay, torch.optim.SGD semantics (dampening 0, no Nesterov):

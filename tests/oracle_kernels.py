@@ -137,6 +137,60 @@ class OracleKernels:
         dw = self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None
         return dx.float(), dw, dg, db
 
+    # ---- GroupNorm / InstanceNorm-fused entry points: float64 group statistics on the host as the checker ----
+    def gn_supported(self, n, c, hw, groups):
+        return groups > 0 and c % groups == 0 and hw % 4 == 0 and (c // groups) * hw <= 24576
+
+    @staticmethod
+    def _gn_xhat(x, groups, stats):
+        n, c = x.shape[0], x.shape[1]
+        x64 = x.detach().double().reshape(n, groups, -1)
+        mean, invstd = stats[:, 0].double().view(n, groups, 1), stats[:, 1].double().view(n, groups, 1)
+        return ((x64 - mean) * invstd).reshape(x.shape)
+
+    def passport_gn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, groups, eps, margin=npp.MARGIN,
+                        l2=npp.L2):
+        n, c = x.shape[0], x.shape[1]
+        x64 = x.detach().double().reshape(n, groups, -1)
+        mean = x64.mean(dim=2)
+        var = x64.var(dim=2, unbiased=False)
+        stats = torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=2).reshape(n * groups, 2).float()
+        if weight is not None:
+            gamma, beta = self.gamma_beta_fwd(weight, m)
+        else:
+            gamma = torch.ones(c) if gamma_in is None else gamma_in.detach().reshape(-1)
+            beta = torch.zeros(c) if beta_in is None else beta_in.detach().reshape(-1)
+        xh = self._gn_xhat(x, groups, stats).float()
+        y = self.affine_relu_fwd(xh, gamma, beta, relu)
+        if b is None:
+            return (y, stats, (gamma if weight is not None else None), (beta if weight is not None else None),
+                    None, None, None)
+        loss, acc, bits = self.sign_loss_fwd(gamma, b, alpha, margin, l2)
+        return y, stats, gamma, beta, loss, acc, bits
+
+    def passport_gn_bwd(self, dy, x, stats, gamma, beta, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu,
+                        groups, margin=npp.MARGIN, l2=npp.L2):
+        n, c = x.shape[0], x.shape[1]
+        g32 = torch.ones(c) if gamma is None else gamma.detach().float().reshape(-1)
+        b32 = torch.zeros(c) if beta is None else beta.detach().float().reshape(-1)
+        xh = self._gn_xhat(x, groups, stats)
+        dy64 = dy.detach().double()
+        z32 = npp.affine_relu_fwd(xh.float().numpy(), g32.numpy(), b32.numpy(), False)
+        dz = torch.where(torch.from_numpy(z32 > 0), dy64, torch.zeros_like(dy64)) if relu else dy64
+        dg, db = (dz * xh).sum(dim=(0, 2, 3)).float(), dz.sum(dim=(0, 2, 3)).float()
+        gz = (dz * g32.double().view(1, -1, 1, 1)).reshape(n, groups, -1)
+        xg = xh.reshape(n, groups, -1)
+        invstd = stats[:, 1].double().view(n, groups, 1)
+        dx = invstd * (gz - gz.mean(dim=2, keepdim=True) - xg * (gz * xg).mean(dim=2, keepdim=True))
+        if dgamma_extra is not None:
+            dg = dg + dgamma_extra
+        if dbeta_extra is not None:
+            db = db + dbeta_extra
+        if dloss is not None:
+            dg = dg + self.sign_loss_bwd(dloss, g32.contiguous(), b, alpha, margin, l2)
+        dw = self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None
+        return dx.reshape(x.shape).float(), dw, dg, db
+
     def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
         with torch.no_grad():
             d = flat_grad * grad_scale + weight_decay * flat_param

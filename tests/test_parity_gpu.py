@@ -392,12 +392,130 @@ def test_fused_bn_layer_equals_unfused_layer_in_a_block(K):
         assert torch.allclose(a(x), b(x), rtol=1e-4, atol=1e-5)
 
 
+# ----------------------------------------------------------------------------- GroupNorm / InstanceNorm-fused layer
+GN_SHAPES = [  # n, c, h, w, groups, kk
+    (64, 384, 8, 8, 24, 1728),      # AlexNet GN (o // 16 groups): 16 channels x 64 = 256 units, one workgroup per chunk
+    (64, 256, 8, 8, 256, 2304),     # AlexNet IN: 16 units, 16 chunks per wavefront
+    (128, 512, 4, 4, 32, 4608),     # ResNet layer4 GN: 64 units
+    (128, 512, 4, 4, 512, 4608),    # ResNet layer4 IN: 4 units (4 lanes per chunk)
+    (6, 64, 32, 32, 4, 27),         # stem GN: 4096 units -> 1024 lanes x 4
+    (5, 64, 32, 32, 64, 27),        # stem IN: 256 units
+    (3, 48, 12, 12, 3, 75),         # 576 units (not a power of two): 1024 lanes, 448 idle
+    (2, 6, 2, 2, 6, 12), (7, 12, 6, 2, 2, 40),   # tiny / ragged last workgroup
+]
+
+
+@pytest.mark.parametrize('mode', ['passport', 'passport_nosign', 'public', 'plain'])
+@pytest.mark.parametrize('shape', GN_SHAPES)
+def test_passport_gn_fused_fwd_bwd(K, shape, mode):
+    """deepipr_passport_gn_fwd/_bwd against float64 group statistics + the numpy passport oracle
+    (tests/oracle_kernels.py): y, stats, dx, dgamma, dbeta, dW.  'plain' = no gamma/beta at all (InstanceNorm2d
+    without affine in a ConvBlock)."""
+    from tests.oracle_kernels import OracleKernels
+    O = OracleKernels()
+    n, c, h, w, groups, kk = shape
+    assert K.gn_supported(n, c, h * w, groups) and O.gn_supported(n, c, h * w, groups)
+    rs = np.random.RandomState(n * 7 + c + groups)
+    x = (rs.standard_normal((n, c, h, w)) * 1.7 + 0.3).astype(np.float32)
+    dy = rs.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((c, kk)) * 0.05).astype(np.float32)
+    m = rs.uniform(-1, 1, (2, kk))
+    b = np.where(rs.uniform(size=c) < 0.5, -1.0, 1.0).astype(np.float32)
+    g_in = (1 + 0.3 * rs.standard_normal(c)).astype(np.float32)
+    b_in = (0.2 * rs.standard_normal(c)).astype(np.float32)
+    dl = np.array(0.7, dtype=np.float32)
+    wless = mode in ('public', 'plain')
+    sign = mode == 'passport'
+
+    def run(kern, to):
+        gi = to(g_in) if mode == 'public' else None
+        bi = to(b_in) if mode == 'public' else None
+        out = kern.passport_gn_fwd(to(x), None if wless else to(wt), None if wless else to(m, torch.float64), gi, bi,
+                                   to(b) if sign else None, ALPHA, True, groups, 1e-5)
+        used_g, used_b = (out[2], out[3]) if not wless else (gi, bi)
+        back = kern.passport_gn_bwd(to(dy), to(x), out[1], used_g, used_b, None if wless else to(m, torch.float64),
+                                    to(b) if sign else None, ALPHA, to(dl) if sign else None, None, None,
+                                    None if wless else (c, kk), True, groups)
+        return out, back
+
+    cpu = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+    o_ref, b_ref = run(O, cpu)
+    o_gpu, b_gpu = run(K, dev)
+    y_r, y_g = o_ref[0].numpy(), host(o_gpu[0])
+    bad = np.abs(y_g - y_r) > 2e-5 * (1 + np.abs(y_r))
+    assert bad.mean() < 1e-5, bad.sum()
+    close(host(o_gpu[1]), o_ref[1].numpy(), 'stats', 5e-6, 5e-6)
+    if not wless:
+        close(host(o_gpu[2]), o_ref[2].numpy(), 'gamma', 2e-6, 2e-6)
+        close(host(o_gpu[3]), o_ref[3].numpy(), 'beta', 2e-6, 2e-6)
+    if sign:
+        assert abs(float(o_gpu[4]) - float(o_ref[4])) < 2e-5 * max(1, abs(float(o_ref[4])))
+        assert float(o_gpu[5]) == pytest.approx(float(o_ref[5]), abs=1e-7)
+        assert np.array_equal(host(o_gpu[6]), o_ref[6].numpy())
+    dx_r, dx_g = b_ref[0].numpy(), host(b_gpu[0])
+    scale = np.abs(dx_r).max() + 1e-12
+    bad = np.abs(dx_g - dx_r) > 1e-4 * scale
+    assert bad.mean() < 1e-4, (bad.sum(), np.abs(dx_g - dx_r).max(), scale)
+    for i, nm in ((2, 'dgamma'), (3, 'dbeta')):
+        ref = b_ref[i].numpy()
+        assert np.abs(host(b_gpu[i]) - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6), nm
+    if not wless:
+        ref = b_ref[1].numpy()
+        assert np.abs(host(b_gpu[1]) - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6)
+    # deterministic
+    o2, b2 = run(K, dev)
+    assert torch.equal(o2[0], o_gpu[0]) and torch.equal(b2[0], b_gpu[0]) and torch.equal(b2[2], b_gpu[2])
+
+
+def test_gn_unsupported_shapes_are_refused_without_side_effects(K):
+    """Chunks beyond the register budget and planes that are not a multiple of 4 floats: gn_supported() says no,
+    the entry point returns DEEPIPR_EUNSUPPORTED, and the layer falls back to the library norm + affine kernels."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    assert not K.gn_supported(8, 64, 56 * 56, 4) and not K.gn_supported(8, 64, 49, 4) and not K.gn_supported(8, 60, 16, 7)
+    x = torch.randn(2, 64, 56, 56, device=DEV)
+    with pytest.raises(RuntimeError, match='does not fit the fused form'):
+        K.passport_gn_fwd(x, None, None, None, None, None, 0.0, True, 4, 1e-5)
+    torch.manual_seed(0)
+    blk = PassportBlock(8, 16, 3, 1, 1, {'norm_type': 'gn', 'key_type': 'random', 'sign_loss': 0.1}).to(DEV)
+    xin = torch.randn(2, 8, 7, 7, device=DEV, requires_grad=True)            # 7x7 planes: unfused path
+    y = blk(xin)
+    (y.sum() + blk.sign_loss.loss).backward()
+    assert torch.isfinite(xin.grad).all() and blk.weight.grad is not None
+
+
+@pytest.mark.parametrize('norm', ['gn', 'in'])
+def test_gn_and_in_layers_take_the_fused_kernels(norm):
+    """AlexNet with norm_type gn / in: all five conv layers (2 ConvBlocks, 3 passport layers) go through
+    k_gn_fwd / k_gn_bwd -- counted by the in-situ profile, so a silent fallback to the library norm would show."""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.alexnet_passport import AlexNetPassport
+    from oracle.cases import alexnet_config
+    kw = construct_passport_kwargs_from_dict({'passport_config': alexnet_config(), 'norm_type': norm,
+                                              'key_type': 'random', 'sl_ratio': ALPHA})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = AlexNetPassport(3, 10, kw).to(DEV).train()
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    net(x)                                                    # materialise keys
+    _lib.profile_enable(True)
+    out = net(x)
+    sl = sum(m.sign_loss.loss for m in net.modules() if hasattr(m, 'sign_loss') and m.sign_loss is not None)
+    (out.sum() + sl).backward()
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    assert prof['gn_fwd'][1] == 5 and prof['gn_bwd'][1] == 5
+    assert prof['affine_fwd'][1] == 0 and prof['affine_bwd'][1] == 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 # ----------------------------------------------------------------------------- golden fixtures (real reference)
 @pytest.mark.parametrize('fuse_norm', [True, False])
 @pytest.mark.parametrize('name', list(CASES))
 def test_model_cases_match_reference_goldens(K, name, fuse_norm, golden_dir):
-    if not fuse_norm and CASES[name]['norm'] != 'bn':
-        pytest.skip('only BatchNorm layers have a fused variant')
+    if not fuse_norm and CASES[name]['norm'] == 'none':
+        pytest.skip('no norm, nothing to fuse')
     """Whole nets + one optimisation step through the product trainers on the GPU, against outputs of the
     real reference.  Logits / losses / gamma / beta within 1e-4, signature bits identical."""
     gold = load_golden(golden_dir, name)
