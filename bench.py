@@ -47,16 +47,16 @@ def build_model(args, device):
         from deepipr_amd.models.alexnet_passport import AlexNetPassport
         from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
         cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'alexnet_passport.json')))
-        kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
-                                                  'sl_ratio': 0.1})
+        kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': getattr(args, 'norm_type', 'bn'),
+                                                  'key_type': 'random', 'sl_ratio': 0.1})
         torch.manual_seed(0)
         np.random.seed(0)
         cls = AlexNetPassport if args.scheme == 1 else AlexNetPassportPrivate
         return cls(3, args.classes, kw, imagenet=getattr(args, 'image_size', 32) > 32).to(device)
     arch = getattr(args, 'arch', 'resnet18')
     cfg = json.load(open(os.path.join(ROOT, 'passport_configs', '%s_passport.json' % arch)))
-    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
-                                              'sl_ratio': 0.1})
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': getattr(args, 'norm_type', 'bn'),
+                                              'key_type': 'random', 'sl_ratio': 0.1})
     torch.manual_seed(0)
     np.random.seed(0)
     if arch == 'resnet50':                       # no reference implementation: see BottleneckPassportBlock
@@ -80,7 +80,7 @@ def fused_layer_elements(model, run_once):
     for m in model.modules():
         if isinstance(m, PASSPORT_TYPES):
             hooks.append(m.register_forward_hook(lambda mod, i, o: (sizes.append(o.numel()), passport.append(o.numel())) and None))
-        elif isinstance(m, ConvBlock) and isinstance(m.bn, torch.nn.BatchNorm2d) and m.fuse_norm:
+        elif isinstance(m, ConvBlock) and m.bn is not None and m.fuse_norm:
             hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel()) and None))
     run_once()
     for h in hooks:
@@ -194,6 +194,8 @@ def main():
     ap.add_argument('--classes', type=int, default=10)
     ap.add_argument('--arch', default='resnet18', choices=['resnet18', 'resnet50', 'alexnet'])
     ap.add_argument('--image-size', type=int, default=32, help='32 = CIFAR shapes, 224 = ImageNet shapes')
+    ap.add_argument('--norm-type', default='bn', choices=['bn', 'gn', 'in'], help="the layers' norm (reference --norm-type)")
+    ap.add_argument('--no-fuse', action='store_true', help='library norm kernels + unfused passport kernels (A/B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
@@ -213,6 +215,10 @@ def main():
     torch.backends.cudnn.benchmark = True                  # MIOpen find-mode, as train_v1.py:8
 
     model = build_model(args, device)
+    if args.no_fuse:
+        for mod in model.modules():
+            if hasattr(mod, 'fuse_norm'):
+                mod.fuse_norm = False
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     nb = 4                                                  # distinct synthetic batches, resident in HBM
     hw = args.image_size
@@ -295,17 +301,21 @@ def main():
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
-        'config': {'workload': '%s V%s passport (%s_passport.json: %d passport layers), '
-                               '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
-                               ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
-                                '1' if args.scheme == 1 else '2 private', args.arch, len(elems), args.classes,
-                                args.image_size, args.image_size, args.batch),
+        'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '
+                                '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
+                                ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
+                                 '1' if args.scheme == 1 else '2 private', args.arch, len(elems), args.classes,
+                                 args.image_size, args.image_size, args.batch)) + (
+                                    '' if args.norm_type == 'bn' else ', norm_type ' + args.norm_type) + (
+                                    ', library norm kernels (--no-fuse)' if args.no_fuse else ''),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': 'hipGraph replay' if args.graph else 'eager'},
     }
-    STREAMING = {'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt)',
+    STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
+                 'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',
+                 'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt)',
                  'bn_res_fwd': 'single-pass norm+affine+ReLU forward: read x once, write y (8 B/elt)',
                  'bn_affine_bwd': 'norm+affine+ReLU backward apply pass: read dy + x, write dx (12 B/elt)',
                  'bn_affine_fwd': 'norm+affine+ReLU forward apply pass (8 B/elt)',

@@ -713,14 +713,24 @@ __global__ __launch_bounds__(kThreads) void k_affine_bwd_large(
 }
 
 // Finish: dgamma[c], dbeta[c] = fixed-order sum of the NS partials.
+// One wavefront per channel: lanes stride over the splits, butterfly at the end (NS reaches the batch size when
+// the partials come from the GroupNorm-fused backward).
 __global__ __launch_bounds__(kThreads) void k_reduce_partials(
     const double *__restrict__ part, int NS, int C, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= 2 * C) return;
-    const int which = i / C, c = i - which * C;
-    double acc = 0.0;
-    for (int sp = 0; sp < NS; ++sp) acc += part[(static_cast<size_t>(sp) * 2 + which) * C + c];
-    (which == 0 ? dgamma : dbeta)[c] = static_cast<float>(acc);
+    const int c = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+    if (c >= C) return;                                   // uniform per wavefront
+    const int lane = threadIdx.x & 63;
+    double ag = 0.0, ab = 0.0;
+    for (int sp = lane; sp < NS; sp += kWave) {
+        ag += part[(static_cast<size_t>(sp) * 2 + 0) * C + c];
+        ab += part[(static_cast<size_t>(sp) * 2 + 1) * C + c];
+    }
+    ag = wave_sum(ag);
+    ab = wave_sum(ab);
+    if (lane == 0) {
+        dgamma[c] = static_cast<float>(ag);
+        dbeta[c] = static_cast<float>(ab);
+    }
 }
 
 // Fused finish of a passport layer's backward: RPW output channels per workgroup.
@@ -1739,23 +1749,33 @@ __global__ void k_gn_bwd(const float4 *__restrict__ dy, const float4 *__restrict
             dx[base + u] = make_float4(st.y * (gz[k].x - c2 - xh[k].x * c3), st.y * (gz[k].y - c2 - xh[k].y * c3),
                                        st.y * (gz[k].z - c2 - xh[k].z * c3), st.y * (gz[k].w - c2 - xh[k].w * c3));
     }
-    // per-channel sums of this workgroup's chunks, one wavefront per (chunk, channel), in unit order
+    // per-channel sums of this workgroup's chunks: `gsz` lanes (a power of two >= min(q4, 64)) per (chunk, channel)
+    // job, 64 / gsz jobs per wavefront pass, fixed order
     __syncthreads();
     const int wave = t >> 6, wl = t & 63, nw = pl.T >> 6;
-    for (int job = wave; job < cpb * pl.cpg; job += nw) {
+    int gsz = 1;
+    while (gsz < pl.q4 && gsz < kWave) gsz <<= 1;
+    const int jpw = kWave / gsz, jobs = cpb * pl.cpg;
+    const int sub = wl / gsz, e0 = wl - sub * gsz;
+    for (int j0 = wave * jpw; j0 < jobs; j0 += nw * jpw) {
+        const int job = j0 + sub;
         const int sl = job / pl.cpg, cc = job - sl * pl.cpg;
         const int ck = blockIdx.x * cpb + sl;
-        if (ck >= pl.chunks) continue;                       // uniform per wavefront
-        const float *p = unit_sums + (static_cast<size_t>(sl) * pl.U + static_cast<size_t>(cc) * pl.q4) * 2;
+        const bool live = job < jobs && ck < pl.chunks;
         double g = 0.0, b = 0.0;
-        for (int e = wl; e < pl.q4; e += kWave) {
-            const float2 q = *reinterpret_cast<const float2 *>(p + static_cast<size_t>(e) * 2);
-            g += static_cast<double>(q.x);
-            b += static_cast<double>(q.y);
+        if (live) {
+            const float *p = unit_sums + (static_cast<size_t>(sl) * pl.U + static_cast<size_t>(cc) * pl.q4) * 2;
+            for (int e = e0; e < pl.q4; e += gsz) {
+                const float2 q = *reinterpret_cast<const float2 *>(p + static_cast<size_t>(e) * 2);
+                g += static_cast<double>(q.x);
+                b += static_cast<double>(q.y);
+            }
         }
-        g = wave_sum(g);
-        b = wave_sum(b);
-        if (wl == 0) {
+        for (int off = gsz >> 1; off > 0; off >>= 1) {
+            g += __shfl_xor(g, off, kWave);
+            b += __shfl_xor(b, off, kWave);
+        }
+        if (live && e0 == 0) {
             const int n = ck / pl.groups, c = (ck - n * pl.groups) * pl.cpg + cc;
             part[(static_cast<size_t>(n) * 2 + 0) * C + c] = g;
             part[(static_cast<size_t>(n) * 2 + 1) * C + c] = b;
@@ -2104,7 +2124,7 @@ int deepipr_affine_relu_bwd(const float *dy, const float *xhat, const float *gam
     int rc = launch_affine_bwd(dy, xhat, gamma, beta, dxhat, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;
     ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
-    DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), st, part,
+    DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((C + 3) / 4), dim3(kThreads), st, part,
                        pl.NS, C, dgamma, dbeta);
     return check_launch("affine_relu_bwd(finish)");
 }
@@ -2320,8 +2340,13 @@ bool plan_gn(int N, int C, int P, int groups, GnPlan *out) {
     const long long U = static_cast<long long>(pl.cpg) * pl.q4;
     if (U > 6144) return false;                    // registers (F4 <= 8 at 1024 lanes) and 48 KB of LDS in backward
     pl.U = static_cast<int>(U);
-    int tg = 1;
-    while (tg < pl.U && tg < 1024) tg <<= 1;
+    // lanes per chunk: ~4 float4 in flight per lane (memory-level parallelism, cheap group reductions), but never
+    // fewer than 16 lanes (256-byte runs per load instruction) unless the chunk itself is shorter
+    auto pow2ceil = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
+    int tg = pow2ceil((pl.U + 3) / 4);
+    const int floor_tg = pow2ceil(pl.U < 16 ? pl.U : 16);
+    if (tg < floor_tg) tg = floor_tg;
+    if (tg > 1024) tg = 1024;
     pl.TG = tg;
     const int need = (pl.U + tg - 1) / tg;
     pl.F4 = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
@@ -2644,7 +2669,7 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
     }
     if (!dW) {
         ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
-        DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((2 * C + kThreads - 1) / kThreads), dim3(kThreads), st, part, N, C,
+        DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((C + 3) / 4), dim3(kThreads), st, part, N, C,
                        dgamma, dbeta);
         return check_launch("passport_gn_bwd(finish)");
     }

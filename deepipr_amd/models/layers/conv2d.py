@@ -12,9 +12,8 @@ import torch
 import torch.nn as nn
 
 
-# Below ~1 M activation elements (4 MB) the six-launch fused pipeline is launch-bound and MIOpen's single-kernel
-# batch norm + ATen ReLU are as fast on the GPU and cheaper on the host (measured: ResNet18 V2 at 32 images/GPU).
-FUSE_MIN_ELEMENTS = 1 << 20
+# Activations smaller than this stay on the library norm + ReLU kernels (override: DEEPIPR_CONVBLOCK_FUSE_MIN).
+FUSE_MIN_ELEMENTS = int(os.environ.get('DEEPIPR_CONVBLOCK_FUSE_MIN', 1 << 20))
 
 
 def make_norm(norm_type, channels, affine):
