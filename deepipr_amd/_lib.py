@@ -45,6 +45,7 @@ SIGNATURES = {
                                     _f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp, _vp]),
     'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
+    'deepipr_relu_bwd2': (_int, [_f32p, _f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,

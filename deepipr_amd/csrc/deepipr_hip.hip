@@ -1839,19 +1839,31 @@ __global__ __launch_bounds__(kThreads) void k_add_relu_fwd(const float *__restri
         out[i] = fmaxf(a[i] + b[i], 0.0f);
 }
 
-__global__ __launch_bounds__(kThreads) void k_relu_bwd(const float *__restrict__ dy, const float *__restrict__ out,
-                                                       float *__restrict__ dx, size_t n) {
+// TWO: the gradient arrives in two pieces (the two consumers of a block's output: the next block's first conv and
+// its identity / projection shortcut); their sum is formed here instead of in a separate add kernel.
+template <bool TWO>
+__global__ __launch_bounds__(kThreads) void k_relu_bwd(const float *__restrict__ dy, const float *__restrict__ dy2,
+                                                       const float *__restrict__ out, float *__restrict__ dx,
+                                                       size_t n) {
     const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
     const size_t n4 = n / 4;
-    const float4 *d4 = reinterpret_cast<const float4 *>(dy), *o4 = reinterpret_cast<const float4 *>(out);
+    const float4 *d4 = reinterpret_cast<const float4 *>(dy), *e4 = reinterpret_cast<const float4 *>(dy2);
+    const float4 *o4 = reinterpret_cast<const float4 *>(out);
     float4 *x4 = reinterpret_cast<float4 *>(dx);
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += step) {
-        const float4 d = d4[i], o = o4[i];
+        float4 d = d4[i];
+        const float4 o = o4[i];
+        if (TWO) {
+            const float4 e = e4[i];
+            d = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+        }
         x4[i] = make_float4(o.x > 0.0f ? d.x : 0.0f, o.y > 0.0f ? d.y : 0.0f, o.z > 0.0f ? d.z : 0.0f,
                             o.w > 0.0f ? d.w : 0.0f);
     }
-    for (size_t i = n4 * 4 + static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += step)
-        dx[i] = out[i] > 0.0f ? dy[i] : 0.0f;
+    for (size_t i = n4 * 4 + static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += step) {
+        const float d = TWO ? dy[i] + dy2[i] : dy[i];
+        dx[i] = out[i] > 0.0f ? d : 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2702,16 +2714,24 @@ int deepipr_add_relu_fwd(const float *a, const float *b, float *out, size_t n, v
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "add_relu_fwd: pointers must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DEEPIPR_K_ADD_RELU, st);
+    prof.bytes = 12.0 * static_cast<double>(n);
     DEEPIPR_LAUNCH(prof, k_add_relu_fwd, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, a, b, out, n);
     return check_launch("add_relu_fwd");
 }
 
 int deepipr_relu_bwd(const float *dy, const float *out, float *dx, size_t n, void *stream) {
+    return deepipr_relu_bwd2(dy, nullptr, out, dx, n, stream);
+}
+
+int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float *dx, size_t n, void *stream) {
     if (!dy || !out || !dx || n == 0) return fail(DEEPIPR_EINVAL, "relu_bwd: bad argument");
-    if (!aligned16(dy) || !aligned16(out) || !aligned16(dx)) return fail(DEEPIPR_EINVAL, "relu_bwd: pointers must be 16-byte aligned");
+    if (!aligned16(dy) || !aligned16(out) || !aligned16(dx) || (dy2 && !aligned16(dy2)))
+        return fail(DEEPIPR_EINVAL, "relu_bwd: pointers must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DEEPIPR_K_ADD_RELU, st);
-    DEEPIPR_LAUNCH(prof, k_relu_bwd, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, dy, out, dx, n);
+    prof.bytes = (dy2 ? 16.0 : 12.0) * static_cast<double>(n);
+    if (dy2) DEEPIPR_LAUNCH(prof, k_relu_bwd<true>, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, dy, dy2, out, dx, n);
+    else DEEPIPR_LAUNCH(prof, k_relu_bwd<false>, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, dy, dy2, out, dx, n);
     return check_launch("relu_bwd");
 }
 

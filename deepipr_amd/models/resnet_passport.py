@@ -56,11 +56,16 @@ class BasicPassportBlock(nn.Module):
             out_y = F.relu(out_y + sc_y)
         return out_x, out_y
 
-    def forward(self, x, force_passport=False, ind=0):
+    def forward_pair(self, x, skip, force_passport=False, ind=0):
+        """The block on (x, skip) = two handles of the same input -- one per consumer, so that the previous block's
+        tail sees their gradients separately (P.add_relu_fork) -- returning two handles of the output."""
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
         out = run_layer(self.convbn_2, out, force_passport, ind)
-        sc = run_layer(self.shortcut, x, force_passport, ind) if self.has_projection() else x
-        return P.add_relu(out, sc)                       # out + shortcut, ReLU: one fused pass on the GPU
+        sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
+        return P.add_relu_fork(out, sc)                  # out + shortcut, ReLU: one fused pass on the GPU
+
+    def forward(self, x, force_passport=False, ind=0):
+        return self.forward_pair(x, x, force_passport, ind)[0]
 
 
 class ResNetPassport(nn.Module):
@@ -108,10 +113,10 @@ class ResNetPassport(nn.Module):
                     x, y = mine.set_intermediate_keys(theirs, x, y)
 
     def forward(self, x, force_passport=False, ind=0):
-        out = self._stem(x, force_passport, ind)
+        out = skip = self._stem(x, force_passport, ind)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for block in layer:
-                out = block(out, force_passport, ind)
+                out, skip = block.forward_pair(out, skip, force_passport, ind)
         out = F.adaptive_avg_pool2d(out, (1, 1))
         return self.linear(out.view(out.size(0), -1))
 
@@ -169,12 +174,15 @@ class BottleneckPassportBlock(nn.Module):
             sc_x, sc_y = x, y
         return F.relu(out_x + sc_x), (F.relu(out_y + sc_y) if y is not None else None)
 
-    def forward(self, x, force_passport=False, ind=0):
+    def forward_pair(self, x, skip, force_passport=False, ind=0):
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
         out = run_layer(self.convbnrelu_2, out, force_passport, ind)
         out = run_layer(self.convbn_3, out, force_passport, ind)
-        sc = run_layer(self.shortcut, x, force_passport, ind) if self.has_projection() else x
-        return P.add_relu(out, sc)
+        sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
+        return P.add_relu_fork(out, sc)
+
+    def forward(self, x, force_passport=False, ind=0):
+        return self.forward_pair(x, x, force_passport, ind)[0]
 
 
 def ResNet50Passport(**model_kwargs):

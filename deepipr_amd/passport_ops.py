@@ -367,12 +367,13 @@ class HipKernels:
                                                       _stream(dev)), 'add_relu_fwd')
         return out
 
-    def relu_bwd(self, dy, out):
-        dev = _chk(dy, out)
+    def relu_bwd(self, dy, out, dy2=None):
+        """(dy [+ dy2]) * [out > 0]."""
+        dev = _chk(dy, out, dy2)
         dx = torch.empty_like(out)
         with _on(dev):
-            _lib.check(_lib.lib().deepipr_relu_bwd(dy.data_ptr(), out.data_ptr(), dx.data_ptr(), out.numel(),
-                                                  _stream(dev)), 'relu_bwd')
+            _lib.check(_lib.lib().deepipr_relu_bwd2(dy.data_ptr(), _p(dy2), out.data_ptr(), dx.data_ptr(),
+                                                   out.numel(), _stream(dev)), 'relu_bwd')
         return dx
 
     def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
@@ -701,12 +702,47 @@ class _AddReLU(torch.autograd.Function):
         return d, d
 
 
+def _add_relu_fusable(a, b):
+    return (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
+            and a.numel() >= ADD_RELU_MIN_ELEMENTS)
+
+
 def add_relu(a, b):
     """relu(a + b) through the fused kernel for same-shape fp32 GPU tensors, the library ops otherwise."""
-    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
-            and a.numel() >= ADD_RELU_MIN_ELEMENTS):
+    if _add_relu_fusable(a, b):
         return _AddReLU.apply(a, b)
     return torch.relu(a + b)
+
+
+class _AddReLUFork(torch.autograd.Function):
+    """relu(a + b) handed out twice -- once for each consumer of a residual block's output (the next block's first
+    conv and its identity / projection shortcut).  Backward therefore receives the two gradients separately and
+    forms (g1 + g2) * [out > 0] in one pass (deepipr_relu_bwd2) instead of autograd's add kernel + the mask pass."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = kernels.add_relu_fwd(a.contiguous(), b.contiguous())
+        ctx.save_for_backward(out)
+        ctx.set_materialize_grads(False)
+        return out, out.detach().view_as(out)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None, None
+        (out,) = ctx.saved_tensors
+        if g1 is None:
+            g1, g2 = g2, None
+        d = kernels.relu_bwd(g1.contiguous(), out, None if g2 is None else g2.contiguous())
+        return d, d
+
+
+def add_relu_fork(a, b):
+    """-> (out, out'): the same values, to be used by the two consumers of a residual block's output."""
+    if _add_relu_fusable(a, b):
+        return _AddReLUFork.apply(a, b)
+    out = torch.relu(a + b)
+    return out, out
 
 
 ADD_RELU_MIN_ELEMENTS = 1 << 18

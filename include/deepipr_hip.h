@@ -248,6 +248,10 @@ int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_b
  * replaces: `out = out + shortcut; out = F.relu(out)`, models/resnet_passport.py:77-84 (private twin :79-86). */
 int deepipr_add_relu_fwd(const float *a, const float *b, float *out, size_t n, void *stream);
 int deepipr_relu_bwd(const float *dy, const float *out, float *dx, size_t n, void *stream);
+/* The same with the incoming gradient in two pieces, d = (dy + dy2) * [out > 0] (16 B/element): `out` feeds two
+ * consumers (the next block's first conv and its shortcut), whose gradients autograd would otherwise add in a
+ * separate kernel (12 B/element more).  dy2 == NULL is deepipr_relu_bwd. */
+int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float *dx, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -901,6 +901,21 @@ def test_add_relu_fused_tail(K, shape):
         a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
         (torch.relu(a2 + b2) * dy).sum().backward()
         assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+        # the forked form: two handles of the output, their gradients summed inside deepipr_relu_bwd2
+        dy2 = dev(rs.standard_normal(shape))
+        assert torch.equal(K.relu_bwd(dy, out, dy2), torch.where(out > 0, dy + dy2, torch.zeros_like(dy)))
+        a3, b3 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        o1, o2 = P.add_relu_fork(a3, b3)
+        assert torch.equal(o1, o2) and o1.data_ptr() == o2.data_ptr()
+        ((o1 * dy).sum() + (o2 * o2 * dy2).sum()).backward()
+        a4, b4 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        o = torch.relu(a4 + b4)
+        ((o * dy).sum() + (o * o * dy2).sum()).backward()
+        assert torch.equal(a3.grad, a4.grad) and torch.equal(b3.grad, b4.grad)
+        a5 = a.clone().requires_grad_(True)
+        o1, o2 = P.add_relu_fork(a5, b)                      # only one consumer contributes a gradient
+        (o2 * dy).sum().backward()
+        assert torch.equal(a5.grad, a2.grad)
 
 
 def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
