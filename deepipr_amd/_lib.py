@@ -50,10 +50,11 @@ SIGNATURES = {
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
                                        _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,
-                                       _f32p, _f32p, _i8p, _vp, _vp, _vp]),
+                                       _f32p, _f32p, _i8p, _f32p, _vp, _vp, _vp]),
     'deepipr_passport_bn_bwd': (_int, [_f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _f32p,
                                        _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _vp,
-                                       _vp, _vp]),
+                                       _vp, _f32p, _f32p, _f32p, _vp]),
+    'deepipr_passport_bn_resident': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_supported': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_gn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _flt, _int,
@@ -64,7 +65,7 @@ SIGNATURES = {
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 SYNC_WORDS = 4096 + 16           # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 4096        # DEEPIPR_SYNC_TIMEOUT_WORD
 

@@ -28,6 +28,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -54,6 +55,12 @@ int fail(int code, const char *fmt, ...) {
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DEEPIPR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    static const bool debug_sync = getenv("DEEPIPR_DEBUG_SYNC") != nullptr;      // triage only: never set in production
+    if (debug_sync) {
+        fprintf(stderr, "[deepipr] %s\n", what);
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail(DEEPIPR_ELAUNCH, "%s (sync): %s", what, hipGetErrorString(e));
+    }
     return DEEPIPR_OK;
 }
 
@@ -1405,7 +1412,7 @@ template <int T, int F4>
 __global__ __launch_bounds__(T) void k_bn_res_fwd(
     const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
     const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
-    unsigned *sync, int with_sign, SignArgs sa) {
+    unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
     constexpr int NW = T / kWave;
     __shared__ double red[2 * NW * 8];
     __shared__ float4 chan[8];
@@ -1489,6 +1496,11 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
                 o = make_float4(bn_affine1<false>(v[k].x, ch), bn_affine1<false>(v[k].y, ch),
                                 bn_affine1<false>(v[k].z, ch), bn_affine1<false>(v[k].w, ch));
             }
+            if (residual) {                          // the block's tail: relu(layer output + shortcut)
+                const float4 r = residual[idx[k]];
+                o = make_float4(fmaxf(o.x + r.x, 0.0f), fmaxf(o.y + r.y, 0.0f), fmaxf(o.z + r.z, 0.0f),
+                                fmaxf(o.w + r.w, 0.0f));
+            }
             y[idx[k]] = o;
         }
     }
@@ -1500,6 +1512,10 @@ struct ResBwdArgs {
     const float *dloss, *dgamma_extra, *dbeta_extra;
     float *dgamma, *dbeta;
     double inv_m;                   // 1/(N*HW); 0 in evaluation mode
+    // fused residual tail (all nullptr when the layer has none): the upstream gradient is (dy + dy2) masked by
+    // tail_out > 0; that masked gradient is also the shortcut's gradient and is written to dres
+    const float4 *dy2, *tail_out;
+    float4 *dres;
 };
 
 __device__ __forceinline__ void res_bwd_prep(float d, float xv, const float4 &ch, int relu, float &dz, float &xh) {
@@ -1535,6 +1551,18 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
             idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
             dz[k] = dy[idx[k]];
             xh[k] = x[idx[k]];
+            if (a.tail_out) {
+                const float4 o = a.tail_out[idx[k]];
+                float4 d = dz[k];
+                if (a.dy2) {
+                    const float4 e = a.dy2[idx[k]];
+                    d = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+                }
+                d = make_float4(o.x > 0.0f ? d.x : 0.0f, o.y > 0.0f ? d.y : 0.0f, o.z > 0.0f ? d.z : 0.0f,
+                                o.w > 0.0f ? d.w : 0.0f);
+                a.dres[idx[k]] = d;
+                dz[k] = d;
+            }
         }
     }
     float a0 = 0.0f, a1 = 0.0f;
@@ -2308,21 +2336,22 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
 
 int launch_res_fwd(const float *x, float *y, const float *gamma, const float *beta, int relu, int N, int C,
                    const ResPlan &pl, const BnFinishArgs &f, double *part, unsigned *sync, bool with_sign,
-                   const SignArgs &sa, hipStream_t st) {
+                   const SignArgs &sa, const float *residual, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
-    prof.bytes = 8.0 * static_cast<double>(N) * C * pl.q4 * 4;
+    prof.bytes = (residual ? 12.0 : 8.0) * static_cast<double>(N) * C * pl.q4 * 4;
+    const float4 *r4 = reinterpret_cast<const float4 *>(residual);
     const dim3 grid(pl.blocks + (with_sign ? 1 : 0));
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     float4 *y4 = reinterpret_cast<float4 *>(y);
     const int ws = with_sign ? 1 : 0;
     if (pl.T == 256) {
-        DEEPIPR_RES_CASES(k_bn_res_fwd, 256, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa)
+        DEEPIPR_RES_CASES(k_bn_res_fwd, 256, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
     } else if (pl.F4 == 12) {
-        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa);
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
     } else if (pl.F4 == 16) {
-        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 16>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa);
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 16>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
     } else {
-        DEEPIPR_RES_CASES(k_bn_res_fwd, 1024, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa)
+        DEEPIPR_RES_CASES(k_bn_res_fwd, 1024, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
     }
     return check_launch("passport_bn_fwd(resident)");
 }
@@ -2330,7 +2359,7 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
 int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
                    const ResPlan &pl, double *part, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
-    prof.bytes = 12.0 * static_cast<double>(N) * C * pl.q4 * 4;
+    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : 12.0) * static_cast<double>(N) * C * pl.q4 * 4;
     const dim3 grid(pl.blocks);
     const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *o4 = reinterpret_cast<float4 *>(dx);
@@ -2389,6 +2418,15 @@ size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW) {
     return two_pass > resident ? two_pass : resident;
 }
 
+int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
+    if (bad_dims(N, C, HW)) return 0;
+    ResPlan rp;
+    int mask = 0;
+    if (plan_resident(N, C, HW, 16, have_sync != 0, &rp)) mask |= 1;
+    if (plan_resident(N, C, HW, 8, have_sync != 0, &rp)) mask |= 2;
+    return mask;
+}
+
 int deepipr_set_resident(int mode) {
     if (mode != 0 && mode != 1) return fail(DEEPIPR_EINVAL, "set_resident: mode must be 0 or 1");
     g_resident_mode.store(mode);
@@ -2400,8 +2438,10 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
                             float *running_mean, float *running_var, long long *num_batches_tracked,
                             float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
                             float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
-                            int8_t *bits, void *workspace, unsigned int *sync, void *stream) {
+                            int8_t *bits, const float *residual, void *workspace, unsigned int *sync,
+                            void *stream) {
     if (!x || !y || !table || bad_dims(N, C, HW)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: bad argument");
+    if (residual && !aligned16(residual)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: residual must be 16-byte aligned");
     if (W && (!m || !gamma || !beta || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: W needs m, gamma, beta, K");
     if (!W && (!gamma_in || !beta_in)) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: need W or gamma_in/beta_in");
     if (training && !workspace) return fail(DEEPIPR_EINVAL, "passport_bn_fwd: training needs a workspace");
@@ -2438,8 +2478,11 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
         f.part = part;
         f.NS = rp.S;
         SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
-        return launch_res_fwd(x, y, g, bt, relu, N, C, rp, f, part, sync, with_sign, sa, st);
+        return launch_res_fwd(x, y, g, bt, relu, N, C, rp, f, part, sync, with_sign, sa, residual, st);
     }
+    if (residual)
+        return fail(DEEPIPR_EUNSUPPORTED, "passport_bn_fwd: the fused residual tail needs the single-pass form "
+                                          "(ask deepipr_passport_bn_resident first)");
     if (training) {
         BwdPlan pl;
         int rc = launch_walk<WALK_STATS>(nullptr, x, nullptr, part, N, C, HW, relu, &pl, st);
@@ -2512,7 +2555,12 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                             float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
-                            unsigned int *sync, void *stream) {
+                            unsigned int *sync, const float *dy2, const float *tail_out, float *dres,
+                            void *stream) {
+    if ((tail_out != nullptr) != (dres != nullptr) || (dy2 && !tail_out))
+        return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tail_out and dres go together (dy2 only with them)");
+    if ((tail_out && !aligned16(tail_out)) || (dres && !aligned16(dres)) || (dy2 && !aligned16(dy2)))
+        return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tail pointers must be 16-byte aligned");
     if (!dy || !x || !table || !dx || !dgamma || !dbeta || !table_out || !workspace || bad_dims(N, C, HW))
         return fail(DEEPIPR_EINVAL, "passport_bn_bwd: bad argument");
     if (dW && (!m || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bn_bwd: dW needs m and K");
@@ -2525,11 +2573,16 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
     if (aligned16(x) && aligned16(dy) && aligned16(dx) && plan_resident(N, C, HW, 8, sync != nullptr, &rp)) {
         // single pass: dz and xhat stay in registers between the two channel sums and the dx phase
         ResBwdArgs a{b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, dgamma, dbeta,
-                     training ? 1.0 / (static_cast<double>(N) * HW) : 0.0};
+                     training ? 1.0 / (static_cast<double>(N) * HW) : 0.0,
+                     reinterpret_cast<const float4 *>(dy2), reinterpret_cast<const float4 *>(tail_out),
+                     reinterpret_cast<float4 *>(dres)};
         int rc = launch_res_bwd(dy, x, table, dx, relu, N, C, rp, part, sync, a, st);
         if (rc != DEEPIPR_OK) return rc;
         return dW ? deepipr_gamma_beta_bwd(dgamma, dbeta, m, C, K, dW, stream) : DEEPIPR_OK;
     }
+    if (tail_out)
+        return fail(DEEPIPR_EUNSUPPORTED, "passport_bn_bwd: the fused residual tail needs the single-pass form "
+                                          "(ask deepipr_passport_bn_resident first)");
     BwdPlan pl;
     int rc = launch_walk<WALK_BN_BWD>(dy, x, table, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;

@@ -23,3 +23,12 @@ def run_layer(layer, x, force_passport, ind):
     if isinstance(layer, PassportBlock):
         return layer(x, force_passport)
     return layer(x)
+
+
+def run_layer_tail(layer, x, residual, force_passport, ind):
+    """`layer` as the last layer of a residual block: -> two handles of relu(layer(x) + residual)."""
+    if isinstance(layer, PassportPrivateBlock):
+        return layer.forward_tail(x, residual, force_passport, ind)
+    if isinstance(layer, PassportBlock):
+        return layer.forward_tail(x, residual, force_passport)
+    return layer.forward_tail(x, residual)

@@ -194,10 +194,24 @@ class PassportLayerBase(nn.Module):
                                       error_msgs)
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, x, force_passport, ind):
+    def _forward(self, x, force_passport, ind, residual=None):
+        """The layer; with `residual` (the shortcut of a residual block whose last layer this is) the pair of handles
+        of relu(layer(x) + residual), folded into the layer's own kernels when they take the single-pass form."""
+        y = self._layer(x, force_passport, ind, residual)
+        if residual is None or isinstance(y, tuple):
+            return y
+        return P.add_relu_fork(y, residual)
+
+    def ensure_key(self, x):
+        """key_type='random': draw the keys lazily from numpy's global RNG at the first input
+        (passportconv2d.py:210-216).  Callable on its own so that a block can keep the reference's draw order
+        (convbnrelu_1, convbn_2, shortcut) while evaluating the shortcut before convbn_2."""
         if (self.get_bias_key() is None and self.key_type == 'random') or self.requires_reset_key:
             self.set_key(torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device),
                          torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device))
+
+    def _layer(self, x, force_passport, ind, residual):
+        self.ensure_key(x)
         x = self.conv(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
@@ -206,12 +220,13 @@ class PassportLayerBase(nn.Module):
         if self.fuse_norm and P.bn_is_fusable(self.bn) and p_scale == p_bias:
             # BatchNorm(affine=False) folded into the passport kernels: 3 launches forward, 3 backward,
             # the normalised activation is never written (deepipr_passport_bn_fwd / _bwd)
+            tail = residual if (residual is not None and P.bn_tail_fusable(self.bn, x)) else None
             if p_scale:
-                return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu)
+                return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail)
             skey, key, m, stride, pad = self._pooled_means()
             y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
                 x, self.weight, skey, key, self.b if sl is not None else None, m, self.bn, self.alpha, relu,
-                stride, pad)
+                stride, pad, tail)
             if sl is not None:
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)

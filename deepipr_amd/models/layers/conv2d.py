@@ -40,12 +40,20 @@ class ConvBlock(nn.Module):
     def reset_parameters(self):
         nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')
 
-    def forward(self, x):
+    def forward_tail(self, x, residual):
+        """-> two handles of relu(self(x) + residual): this block as the last one of a residual block; the add and
+        the outer ReLU are folded into the norm kernels when they take the single-pass form."""
+        from deepipr_amd import passport_ops as P
+        y = self.forward(x, residual)
+        return y if isinstance(y, tuple) else P.add_relu_fork(y, residual)
+
+    def forward(self, x, _residual=None):
         x = self.conv(x)
         if (self.fuse_norm and x.is_cuda and x.numel() >= FUSE_MIN_ELEMENTS and isinstance(self.bn, nn.BatchNorm2d)
                 and self.bn.affine and self.bn.momentum is not None and x.dtype == torch.float32):
             from deepipr_amd import passport_ops as P
-            return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None)
+            tail = _residual if (_residual is not None and P.bn_tail_fusable(self.bn, x)) else None
+            return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None, tail)
         if self.fuse_norm and isinstance(self.bn, (nn.GroupNorm, nn.InstanceNorm2d)) and x.is_cuda:
             from deepipr_amd import passport_ops as P
             if P.gn_is_fusable(self.bn, x):          # GroupNorm(affine) / InstanceNorm2d + ReLU in one kernel

@@ -25,3 +25,7 @@ class PassportBlock(PassportLayerBase):
 
     def forward(self, x, force_passport=False):
         return self._forward(x, force_passport, 0)
+
+    def forward_tail(self, x, residual, force_passport=False):
+        """-> two handles of relu(self(x) + residual): this layer as the last one of a residual block."""
+        return self._forward(x, force_passport, 0, residual)

@@ -16,3 +16,7 @@ class PassportPrivateBlock(PassportLayerBase):
 
     def forward(self, x, force_passport=False, ind=0):
         return self._forward(x, force_passport, ind)
+
+    def forward_tail(self, x, residual, force_passport=False, ind=0):
+        """-> two handles of relu(self(x) + residual): this layer as the last one of a residual block."""
+        return self._forward(x, force_passport, ind, residual)

@@ -11,8 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from deepipr_amd import passport_ops as P
-from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer
+from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer, run_layer_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 
 
@@ -58,11 +57,13 @@ class BasicPassportBlock(nn.Module):
 
     def forward_pair(self, x, skip, force_passport=False, ind=0):
         """The block on (x, skip) = two handles of the same input -- one per consumer, so that the previous block's
-        tail sees their gradients separately (P.add_relu_fork) -- returning two handles of the output."""
+        tail sees their gradients separately (passport_ops.add_relu_fork) -- returning two handles of the output."""
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
-        out = run_layer(self.convbn_2, out, force_passport, ind)
+        if isinstance(self.convbn_2, PASSPORT_TYPES):
+            self.convbn_2.ensure_key(out)                # lazily drawn random keys: the reference's layer order
         sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
-        return P.add_relu_fork(out, sc)                  # out + shortcut, ReLU: one fused pass on the GPU
+        # convbn_2, + shortcut, ReLU: folded into convbn_2's own norm kernels when they take the single-pass form
+        return run_layer_tail(self.convbn_2, out, sc, force_passport, ind)
 
     def forward(self, x, force_passport=False, ind=0):
         return self.forward_pair(x, x, force_passport, ind)[0]
@@ -177,9 +178,10 @@ class BottleneckPassportBlock(nn.Module):
     def forward_pair(self, x, skip, force_passport=False, ind=0):
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
         out = run_layer(self.convbnrelu_2, out, force_passport, ind)
-        out = run_layer(self.convbn_3, out, force_passport, ind)
+        if isinstance(self.convbn_3, PASSPORT_TYPES):
+            self.convbn_3.ensure_key(out)
         sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
-        return P.add_relu_fork(out, sc)
+        return run_layer_tail(self.convbn_3, out, sc, force_passport, ind)
 
     def forward(self, x, force_passport=False, ind=0):
         return self.forward_pair(x, x, force_passport, ind)[0]

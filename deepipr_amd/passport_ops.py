@@ -10,6 +10,8 @@ Reference lines each operator stands in for (paths relative to kamwoh/DeepIPR):
   sign_loss           models/losses/sign_loss.py:18-54
   passport_layer      all of the above in two launches forward, two backward
 """
+import os
+
 import torch
 
 from deepipr_amd import _lib
@@ -241,11 +243,22 @@ class HipKernels:
         """Number of (device, stream) exchange buffers whose bounded in-kernel wait ever expired (0 = healthy)."""
         return sum(int(buf[_lib.SYNC_TIMEOUT_WORD].item() != 0) for buf in self._sync.values())
 
+    _resident = {}
+
+    def bn_resident(self, n, c, hw):
+        """Bit 0 / 1: forward / backward of this shape take the single-pass kernels (deepipr_passport_bn_resident)."""
+        key = (n, c, hw, self.allow_sync)
+        v = self._resident.get(key)
+        if v is None:
+            v = self._resident[key] = _lib.lib().deepipr_passport_bn_resident(n, c, hw, int(self.allow_sync))
+        return v
+
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
-                        momentum, eps, training, margin=MARGIN, l2=L2):
-        """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x.
+                        momentum, eps, training, margin=MARGIN, l2=L2, residual=None):
+        """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x; with `residual`
+        (single-pass shapes only) y = relu(that + residual), the tail of a residual block.
         -> y, table[C,8], gamma, beta, loss, acc, bits  (gamma/beta None on the W-less public branch)."""
-        dev = _chk(x, weight)                     # the small per-channel vectors come from this module's own code
+        dev = _chk(x, weight, residual)                     # the small per-channel vectors come from this module's own code
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
@@ -267,8 +280,8 @@ class HipKernels:
                 x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
                 _p(running_mean), _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu),
                 y.data_ptr(), base, p_gamma if weight is not None else None, p_beta if weight is not None else None,
-                p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), ws,
-                self._sync_words(dev, st) if training else None, st), 'passport_bn_fwd')
+                p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), _p(residual),
+                ws, self._sync_words(dev, st) if training else None, st), 'passport_bn_fwd')
         table = small[:8 * c].view(c, 8)
         gamma = beta = loss = acc = None
         if weight is not None:
@@ -278,9 +291,10 @@ class HipKernels:
         return y, table, gamma, beta, loss, acc, bits
 
     def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
-                        margin=MARGIN, l2=L2):
-        """-> dx, dW (None when wshape is None), dgamma, dbeta."""
-        dev = _chk(dy, x)
+                        margin=MARGIN, l2=L2, dy2=None, tail_out=None):
+        """-> dx, dW (None when wshape is None), dgamma, dbeta [, dres when tail_out is given: the fused residual
+        tail, dres = (dy + dy2) * [tail_out > 0] is the shortcut's gradient]."""
+        dev = _chk(dy, x, dy2, tail_out)
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
@@ -291,12 +305,16 @@ class HipKernels:
         dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         pg = dgb.data_ptr()
+        dres = torch.empty_like(x) if tail_out is not None else None
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_bwd(
                 dy.data_ptr(), x.data_ptr(), table.data_ptr(), _p(m), _p(b), alpha, margin, l2, _p(dloss),
                 _p(dgamma_extra), _p(dbeta_extra), int(training), n, c, hw,
                 (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c,
-                scratch + nws, scratch, self._sync_words(dev, st), st), 'passport_bn_bwd')
+                scratch + nws, scratch, self._sync_words(dev, st), _p(dy2), _p(tail_out), _p(dres), st),
+                'passport_bn_bwd')
+        if tail_out is not None:
+            return dx, dw, dgb[0], dgb[1], dres
         return dx, dw, dgb[0], dgb[1]
 
     # ---- GroupNorm / InstanceNorm-fused layer (include/deepipr_hip.h: deepipr_passport_gn_*) ----
@@ -535,22 +553,27 @@ class _PassportLayer(torch.autograd.Function):
 
 
 class _PassportBNLayer(torch.autograd.Function):
-    """BatchNorm2d(affine=False) + passport affine + ReLU + sign loss, fused: three launches forward, three
-    backward, the normalised activation is never written.  With weight=None it is the public branch of a
-    PassportPrivateBlock (learnable gamma_in / beta_in)."""
+    """BatchNorm2d(affine=False) + passport affine + ReLU + sign loss, fused (deepipr_passport_bn_fwd / _bwd): one
+    register-resident launch per direction when the activation fits, three otherwise; the normalised activation
+    is never written.  With weight=None it is the public branch of a PassportPrivateBlock (learnable gamma_in /
+    beta_in).  With `residual` the block's tail relu(layer + residual) is folded in as well.  The output comes
+    out twice (y, y'): two handles of the same tensor for the two consumers of a residual block's output, whose
+    gradients are then summed inside the backward kernel (tail form) instead of by an ATen add."""
 
     @staticmethod
-    def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, cfg):
+    def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, residual, cfg):
         alpha, relu, stride, pad, training, momentum, eps = cfg
         x = x.contiguous()
         w = None if weight is None else weight.contiguous()
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
+        res = None if residual is None else residual.contiguous()
         y, table, gamma, beta, loss, acc, bits = kernels.passport_bn_fwd(
             x, w, m, gi, bi, bb, float(alpha), relu, running_mean, running_var, nbt, float(momentum), float(eps),
-            training)
-        ctx.save_for_backward(x, w, table, m, bb)
+            training, residual=res)
+        ctx.tail = res is not None
+        ctx.save_for_backward(x, w, table, m, bb, y if ctx.tail else None)
         ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
         ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as freshly filled zeros
         # running_mean / running_var / num_batches_tracked are plain buffers updated in place by the kernel
@@ -560,39 +583,70 @@ class _PassportBNLayer(torch.autograd.Function):
             loss = acc = x.new_empty(0)
             bits = torch.empty(0, dtype=torch.int8, device=x.device)
         ctx.mark_non_differentiable(acc, bits)
-        return y, gamma, beta, loss, acc, bits
+        return y, y.detach().view_as(y), gamma, beta, loss, acc, bits
 
     @staticmethod
-    def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
-        x, w, table, m, bb = ctx.saved_tensors
+    def backward(ctx, dy, dy2, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
+        x, w, table, m, bb, tail_out = ctx.saved_tensors
         alpha, relu, stride, pad, training, key_shape = ctx.cfg
         if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
             dy = torch.zeros_like(x)
+        if dy2 is not None and not ctx.tail:
+            dy, dy2 = dy + dy2, None
         dl = None if (bb is None or dloss is None) else dloss.contiguous()
         if w is None:
             dgamma_extra = dbeta_extra = None
-        dx, dw, dg, db = kernels.passport_bn_bwd(dy.contiguous(), x, table, m, bb, alpha, dl,
-                                                 _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
-                                                 None if w is None else w.shape, relu, training)
+        out = kernels.passport_bn_bwd(dy.contiguous(), x, table, m, bb, alpha, dl,
+                                      _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
+                                      None if w is None else w.shape, relu, training,
+                                      dy2=None if dy2 is None else dy2.contiguous(), tail_out=tail_out)
+        dx, dw, dg, db = out[:4]
+        dres = out[4] if ctx.tail else None
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
         return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
-                dg if w is None else None, db if w is None else None, None, None, None, None, None, None)
+                dg if w is None else None, db if w is None else None, None, None, None, None, None, dres, None)
 
 
-def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad):
-    """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False)."""
+def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual):
     cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps)
-    return _PassportBNLayer.apply(x, weight, skey, key, None, None, b, m, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked if bn.training else None, cfg)
+    return _PassportBNLayer.apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked if bn.training else None, residual, cfg)
 
 
-def bn_affine_relu(x, gamma, beta, bn, relu=True):
-    """Fused public branch: BatchNorm2d(affine=False) + learnable gamma/beta + ReLU."""
-    cfg = (0.0, bool(relu), 1, 0, _bn_uses_batch_stats(bn), bn.momentum, bn.eps)
-    return _PassportBNLayer.apply(x, None, None, None, gamma, beta, None, None, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked if bn.training else None, cfg)[0]
+def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None):
+    """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False).
+    -> y, gamma, beta, loss, acc, bits; with `residual` y is the PAIR of handles of relu(layer + residual)."""
+    y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, None, None, b, m, bn, alpha, relu, stride,
+                                                    pad, residual)
+    return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
+
+
+def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None):
+    """Fused public branch: BatchNorm2d(affine=False) + learnable gamma/beta + ReLU; with `residual` the pair of
+    handles of relu(that + residual)."""
+    out = _bn_apply(x, None, None, None, gamma, beta, None, None, bn, 0.0, relu, 1, 0, residual)
+    return (out[0], out[1]) if residual is not None else out[0]
+
+
+def bn_tail_fusable(bn, x):
+    """The residual tail can be folded into this layer's kernels: a BatchNorm2d on batch statistics and a shape
+    that takes the single-pass form in both directions."""
+    # Opt-in (DEEPIPR_TAIL_FUSION=1).  Measured +1.1 % on config R and bit-identical to the separate kernels, but with
+    # it enabled one sequence of the GPU test suite (a find-mode step, deterministic-mode steps, a find-mode step in one
+    # process) ends in "MIOpen Error: HIP runtime error: invalid argument" inside the backward-data of a 1x1 stride-2
+    # shortcut convolution; not understood yet (DESIGN.md 7), so the separate tail kernels stay the default.
+    if os.environ.get('DEEPIPR_TAIL_FUSION') != '1':
+        return False
+    if not isinstance(bn, torch.nn.BatchNorm2d) or bn.momentum is None or not _bn_uses_batch_stats(bn):
+        return False
+    if x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    n, c = x.shape[0], x.shape[1]
+    return kernels.bn_resident(n, c, x.numel() // (n * c)) == 3
 
 
 def _bn_uses_batch_stats(bn):

@@ -30,7 +30,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 2
+#define DEEPIPR_ABI_VERSION 3
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -185,22 +185,35 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * sync == NULL whenever another kernel may occupy CUs of the device at the same time (e.g. a collective on a
  * second stream); channel-owning layers (C >= CUs) then still take the single pass, the others the 3-launch
  * form.  word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero if a bounded in-kernel wait ever expired.
- * deepipr_set_resident(0) disables the single-pass kernels process-wide (testing), (1) restores the default. */
+ * deepipr_set_resident(0) disables the single-pass kernels process-wide (testing), (1) restores the default.
+ *
+ * Fused residual tail (single-pass form only).  The last layer of a residual block is followed by
+ * `out = relu(layer(x) + shortcut)` (models/resnet_passport.py:77-84).  forward: residual != NULL makes the kernel
+ * write that `out` into y directly (reads x and the shortcut, 12 B/element, the layer's own output is never
+ * written).  backward: tail_out = that `out`, dy (+ optional dy2: `out` has two consumers, see
+ * deepipr_relu_bwd2) the gradient w.r.t. it; the kernel forms d = (dy + dy2) * [tail_out > 0], writes it to dres
+ * (the shortcut's gradient) and continues with d as the layer's upstream gradient (20-24 B/element instead of
+ * 28 in two kernels).  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
+ * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
+ * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
 #define DEEPIPR_SYNC_WORDS (4096 + 16)
 #define DEEPIPR_SYNC_TIMEOUT_WORD 4096
 int deepipr_set_resident(int mode);
+int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
                             const float *beta_in, const float *b, float alpha, float margin, float l2,
                             float *running_mean, float *running_var, long long *num_batches_tracked,
                             float momentum, float eps, int training, int N, int C, int HW, int K, int relu,
                             float *y, float *table, float *gamma, float *beta, float *loss, float *acc,
-                            int8_t *bits, void *workspace, unsigned int *sync, void *stream);
+                            int8_t *bits, const float *residual, void *workspace, unsigned int *sync,
+                            void *stream);
 int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table, const double *m, const float *b,
                             float alpha, float margin, float l2, const float *dloss, const float *dgamma_extra,
                             const float *dbeta_extra, int training, int N, int C, int HW, int K, int relu,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
-                            unsigned int *sync, void *stream);
+                            unsigned int *sync, const float *dy2, const float *tail_out, float *dres,
+                            void *stream);
 
 /* ------------------------------------------------------------------ GroupNorm / InstanceNorm-fused passport layer
  * The passport layer's other norms are GroupNorm(o // 16, o, affine=False) and InstanceNorm2d(o)

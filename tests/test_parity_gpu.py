@@ -392,6 +392,68 @@ def test_fused_bn_layer_equals_unfused_layer_in_a_block(K):
         assert torch.allclose(a(x), b(x), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('shape', [(128, 64, 32, 32, 27), (128, 128, 16, 16, 576), (128, 512, 4, 4, 4608), (33, 256, 8, 8, 1152)])
+@pytest.mark.parametrize('mode', ['passport', 'public'])
+def test_fused_residual_tail_equals_separate_kernels(K, shape, mode):
+    """out = relu(layer(x) + shortcut) folded into the single-pass norm kernels (forward: residual; backward:
+    dy + dy2 masked by out, also returned as the shortcut's gradient) is bit-identical to the layer followed by
+    deepipr_add_relu_fwd / deepipr_relu_bwd2."""
+    n, c, h, w, kk = shape
+    assert K.bn_resident(n, c, h * w) == 3
+    rs = np.random.RandomState(c + n)
+    x, r, g1, g2 = [dev(rs.standard_normal((n, c, h, w))) for _ in range(4)]
+    wt = dev(rs.standard_normal((c, kk)) * 0.05)
+    m = dev(rs.uniform(-1, 1, (2, kk)), torch.float64)
+    b = dev(np.where(rs.uniform(size=c) < 0.5, -1.0, 1.0))
+    gi, bi = dev(1 + 0.3 * rs.standard_normal(c)), dev(0.2 * rs.standard_normal(c))
+    dl = dev(np.array(0.7))
+    public = mode == 'public'
+
+    def fwd(residual):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        return K.passport_bn_fwd(x, None if public else wt, None if public else m, gi if public else None,
+                                 bi if public else None, None if public else b, ALPHA, True, rm, rv, None, 0.1, 1e-5,
+                                 True, residual=residual)
+
+    def bwd(table, dy, **kw):
+        return K.passport_bn_bwd(dy, x, table, None if public else m, None if public else b, ALPHA,
+                                 None if public else dl, None, None, None if public else (c, kk), True, True, **kw)
+
+    plain, fused = fwd(None), fwd(r)
+    out = K.add_relu_fwd(plain[0], r)
+    assert torch.equal(fused[0], out)
+    assert torch.equal(fused[1], plain[1])
+    for second in (g2, None):
+        d = K.relu_bwd(g1, out, second)
+        ref = bwd(plain[1], d)
+        got = bwd(fused[1], g1, dy2=second, tail_out=fused[0])
+        assert torch.equal(got[4], d)
+        for a_, b_ in zip(got[:4], ref):
+            if a_ is not None:
+                assert torch.equal(a_, b_)
+
+
+def test_residual_blocks_use_the_fused_tail():
+    """A ResNet18 train step on the GPU with the opt-in tail fusion (DEEPIPR_TAIL_FUSION=1): the 8 block tails go
+    through the norm kernels, no k_add_relu / k_relu_bwd launches are left.  Skipped unless the switch is set (run it
+    on its own: see passport_ops.bn_tail_fusable for why the fusion is not the default)."""
+    import os
+    if os.environ.get('DEEPIPR_TAIL_FUSION') != '1':
+        pytest.skip('tail fusion is opt-in')
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.trainer import train_step_v1
+    prod, _ref, x, y = _fullsize_pair(False, 128, 10)     # config R: every norm layer above the ConvBlock fusion size
+    opt = torch.optim.SGD(prod.parameters(), lr=0.0)
+    train_step_v1(prod, opt, x.to(DEV), y.to(DEV))
+    _lib.profile_enable(True)
+    train_step_v1(prod, opt, x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    assert prof['add_relu'][1] == 0, prof['add_relu']
+    assert prof['bn_res_fwd'][1] == 20 and prof['bn_res_bwd'][1] == 20
+
+
 # ----------------------------------------------------------------------------- GroupNorm / InstanceNorm-fused layer
 GN_SHAPES = [  # n, c, h, w, groups, kk
     (64, 384, 8, 8, 24, 1728),      # AlexNet GN (o // 16 groups): 16 channels x 64 = 256 units, one workgroup per chunk
