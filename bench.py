@@ -196,10 +196,12 @@ def main():
     ap.add_argument('--image-size', type=int, default=32, help='32 = CIFAR shapes, 224 = ImageNet shapes')
     ap.add_argument('--norm-type', default='bn', choices=['bn', 'gn', 'in'], help="the layers' norm (reference --norm-type)")
     ap.add_argument('--no-fuse', action='store_true', help='library norm kernels + unfused passport kernels (A/B)')
+    ap.add_argument('--no-miopen-find', action='store_true', help='cudnn.benchmark = False: MIOpen immediate mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph (1 GPU only)')
+    ap.add_argument('--graph', action='store_true', help='hipGraph replay of the step (the default on one GPU)')
+    ap.add_argument('--eager', action='store_true', help='eager dispatch of the timed region also on one GPU')
     ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
     ap.add_argument('--ddp-static-graph', type=int, default=1, help='DistributedDataParallel(static_graph=...)')
     args = ap.parse_args()
@@ -212,7 +214,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True                  # MIOpen find-mode, as train_v1.py:8
+    torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find-mode, as train_v1.py:8
 
     model = build_model(args, device)
     if args.no_fuse:
@@ -247,28 +249,41 @@ def main():
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
 
     all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
-    if args.graph:
-        assert not args.ddp, '--graph works with FlatSGD, not with DistributedDataParallel hooks'
-        from deepipr_amd.experiments.graph_step import GraphedTrainStep
-        fn = train_step_v1 if args.scheme == 1 else train_step_v23
-        import torch.distributed as tdist
-        graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
-        step = lambda i: graphed(xs[i % nb], ys[i % nb])
-        args.no_kernel_timing = True                       # per-dispatch events cannot be captured
+    # Launch mode of the timed region.  One GPU: the whole step (zero_grad .. optimiser) is replayed from a hipGraph
+    # by default -- the step issues ~280 dispatches, and on a box with a slow or busy host the eager enqueue
+    # (4.5-6.5 ms) rather than the GPU (5.6 ms) sets the pace; replay takes the host out of the measurement.
+    # Several GPUs: eager, so that FlatSGD's bucketed all-reduces overlap with backward (--graph replays forward +
+    # backward and runs the exchange eagerly after it).  --eager forces eager everywhere.
+    eager_step = step
+    use_graph = (args.graph or (args.gpus == 1 and not args.eager)) and not args.ddp
+    if use_graph:
+        try:
+            from deepipr_amd.experiments.graph_step import GraphedTrainStep
+            fn = train_step_v1 if args.scheme == 1 else train_step_v23
+            import torch.distributed as tdist
+            graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
+            step = lambda i: graphed(xs[i % nb], ys[i % nb])
+        except Exception as exc:                           # capture refused: measure the eager step instead
+            print('bench.py: hipGraph capture failed (%s: %s); timing the eager step' % (type(exc).__name__, exc),
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph, step = False, eager_step
     for i in range(args.warmup):
         step(i)
     timing = not args.no_kernel_timing
     D.barrier()
     torch.cuda.synchronize()
-    # in-situ kernel timing on every `stride`-th step of the timed region (dispatching with per-kernel events
-    # costs ~0.8 ms of host time on such a step; sampling keeps the timed region within ~1 % of an untimed one)
+    # In-situ kernel timing: start/stop events on each kernel's own dispatch.  Eager timed region: on every
+    # `stride`-th step of it (dispatching with per-kernel events costs ~0.8 ms of host time on such a step;
+    # sampling keeps the region within ~1 % of an untimed one).  Graph-replayed timed region: per-dispatch events
+    # cannot be captured, so the same steps are run eagerly right AFTER the timed region and every one is timed.
     stride = max(1, min(10, args.steps // 3))
     if timing:
         _lib.profile_enable(1)
         _lib.profile_enable(0)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timing and i % stride == 0:
+        if timing and not use_graph and i % stride == 0:
             _lib.profile_enable(2)
             step(i)
             _lib.profile_enable(0)
@@ -277,6 +292,17 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
+    sampled = len(range(0, args.steps, stride))
+    if timing and use_graph:
+        sampled = min(args.steps, 30)
+        for i in range(3):
+            eager_step(i)                                  # back to eager dispatch: allocator / MIOpen handles warm
+        torch.cuda.synchronize()
+        _lib.profile_enable(2)
+        for i in range(sampled):
+            eager_step(i)
+        torch.cuda.synchronize()
+        _lib.profile_enable(0)
     prof = _lib.profile_read() if timing else {}
     prof_bytes = _lib.profile_read_bytes() if timing else {}
     if timing:
@@ -311,7 +337,8 @@ def main():
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
-                   'launch': 'hipGraph replay' if args.graph else 'eager'},
+                   'launch': ('hipGraph replay of the whole step; kernel timing from %d eager steps right after the timed '
+                              'region' % sampled) if use_graph else 'eager'},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
                  'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',
@@ -327,7 +354,6 @@ def main():
         # kernel execution time, comparable with rocprofv3's kernel trace.  The library also accounts the
         # algorithmic bytes of every timed launch (deepipr_profile_read_bytes), so achieved = bytes / kernel time
         # summed over exactly the launches that were timed.
-        sampled = len(range(0, args.steps, stride))
         kern = {}
         for name in STREAMING:
             ms, n = prof.get(name, (0.0, 0))

@@ -4,8 +4,10 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${ROUND_TAG:-r01}
-timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/pytest_gpu.log
-tail -3 gpurun_out/pytest_gpu.log
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/pytest_gpu.log
+  tail -3 gpurun_out/pytest_gpu.log
+fi
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log | cut -c1-300
 cd /tmp
