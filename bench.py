@@ -11,8 +11,10 @@ zero_grad -> forward -> CE + sum of sign losses -> backward -> SGD(0.01, 0.9, wd
 (reference experiments/trainer.py:128-145).  Weak scaling: every rank keeps a batch of 128.
 
 Rank 0 prints ONE JSON line with the whole-job images/sec, plus
-  roofline      the dominant hand-written kernel (passport affine backward), timed in situ with HIP
-                events on its launch stream during the timed region
+  roofline      the dominant hand-written kernel (single-pass norm + passport affine + ReLU backward), timed in
+                situ with start/stop HIP events on each dispatch of it, on its launch stream: during the timed
+                region when that runs eagerly (several GPUs, --eager), on eager steps of the same job right after it
+                when the timed region is replayed from a hipGraph (the one-GPU default; config.launch says which)
   cpu_baseline  the oracle's CPU step ("port") on this host's cores, bounded sample, N=1 only
 """
 import argparse
