@@ -4,8 +4,9 @@
 # (DEEPIPR_FORCE_DDP=1), the hipGraph (forward+backward) + eager exchange form, and the DDP alternative.
 export DEEPIPR_FORCE_DDP=1
 RUN="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511"
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress 2>&1 | grep '"metric"' | cut -c1-200
+# (with --gpus 1 bench.py would default to graph replay: --eager = what N > 1 ranks run)
+$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --eager 2>&1 | grep '"metric"' | cut -c1-200
 $RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --graph 2>&1 | grep -E '"metric"|Error' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --scheme 2 --classes 100 --batch 32 2>&1 | grep '"metric"' | cut -c1-200
+$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --scheme 2 --classes 100 --batch 32 --eager 2>&1 | grep '"metric"' | cut -c1-200
 $RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --scheme 2 --classes 100 --batch 32 --graph 2>&1 | grep -E '"metric"|Error' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --ddp 2>&1 | grep '"metric"' | cut -c1-200
+$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --ddp --eager 2>&1 | grep '"metric"' | cut -c1-200
