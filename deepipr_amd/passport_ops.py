@@ -635,11 +635,9 @@ def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None):
 def bn_tail_fusable(bn, x):
     """The residual tail can be folded into this layer's kernels: a BatchNorm2d on batch statistics and a shape
     that takes the single-pass form in both directions."""
-    # Opt-in (DEEPIPR_TAIL_FUSION=1).  Measured +1.1 % on config R and bit-identical to the separate kernels, but with
-    # it enabled one sequence of the GPU test suite (a find-mode step, deterministic-mode steps, a find-mode step in one
-    # process) ends in "MIOpen Error: HIP runtime error: invalid argument" inside the backward-data of a 1x1 stride-2
-    # shortcut convolution; not understood yet (DESIGN.md 7), so the separate tail kernels stay the default.
-    if os.environ.get('DEEPIPR_TAIL_FUSION') != '1':
+    # DEEPIPR_TAIL_FUSION=0 keeps the separate tail kernels (deepipr_add_relu_fwd / deepipr_relu_bwd2); both forms are
+    # bit-identical (tests/test_parity_gpu.py::test_tail_fusion_is_bit_identical_at_model_level).
+    if os.environ.get('DEEPIPR_TAIL_FUSION', '1') == '0':
         return False
     if not isinstance(bn, torch.nn.BatchNorm2d) or bn.momentum is None or not _bn_uses_batch_stats(bn):
         return False

