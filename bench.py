@@ -73,6 +73,10 @@ def build_model(args, device):
     return model.to(device)
 
 
+def _numel(out):
+    return (out[0] if isinstance(out, tuple) else out).numel()      # a block's last layer returns its output twice
+
+
 def fused_layer_elements(model, run_once):
     """Activation elements of every layer call that goes through the fused norm+affine kernels during one
     step (passport layers and BatchNorm ConvBlocks), for the algorithmic byte count.  -> (all, passport only)"""
@@ -81,9 +85,9 @@ def fused_layer_elements(model, run_once):
     hooks = []
     for m in model.modules():
         if isinstance(m, PASSPORT_TYPES):
-            hooks.append(m.register_forward_hook(lambda mod, i, o: (sizes.append(o.numel()), passport.append(o.numel())) and None))
+            hooks.append(m.register_forward_hook(lambda mod, i, o: (sizes.append(_numel(o)), passport.append(_numel(o))) and None))
         elif isinstance(m, ConvBlock) and m.bn is not None and m.fuse_norm:
-            hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel()) and None))
+            hooks.append(m.register_forward_hook(lambda mod, i, o: sizes.append(_numel(o)) and None))
     run_once()
     for h in hooks:
         h.remove()
@@ -344,8 +348,8 @@ def main():
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
                  'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',
-                 'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt)',
-                 'bn_res_fwd': 'single-pass norm+affine+ReLU forward: read x once, write y (8 B/elt)',
+                 'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt; 20-24 with a folded residual tail)',
+                 'bn_res_fwd': 'single-pass norm+affine+ReLU forward: read x once, write y (8 B/elt; 12 with a folded residual tail)',
                  'bn_affine_bwd': 'norm+affine+ReLU backward apply pass: read dy + x, write dx (12 B/elt)',
                  'bn_affine_fwd': 'norm+affine+ReLU forward apply pass (8 B/elt)',
                  'bn_bwd_reduce': 'backward channel sums (8 B/elt)', 'bn_stats': 'batch statistics (4 B/elt)',
@@ -375,9 +379,13 @@ def main():
         dom = max((k for k in kern if k in STREAMING and k != 'sgd'), key=lambda k: kern[k]['us_per_step'])
         a = kern[dom]
         per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
+        # PMC traffic (profiles/pmc_traffic.json) was collected per shape for the plain single pass; with the residual
+        # tails folded into 8 of the 20 launches the step's mix moves more bytes per launch, so it is quoted only when
+        # it describes the same launch mix (the per-shape PMC / algorithmic ratios are in DESIGN.md 4)
+        pmc_bytes = pmc_traffic('k_' + dom, 'in_situ_per_launch')
         out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
-                           'traffic': pmc_traffic('k_' + dom, 'in_situ_per_launch'),
+                           'traffic': pmc_bytes if pmc_bytes and abs(pmc_bytes / per_launch - 1.0) < 0.05 else None,
                            'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
                            'launches_per_step': a['launches_per_step'],
                            'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '

@@ -44,7 +44,7 @@ class ConvBlock(nn.Module):
         """-> two handles of relu(self(x) + residual): this block as the last one of a residual block; the add and
         the outer ReLU are folded into the norm kernels when they take the single-pass form."""
         from deepipr_amd import passport_ops as P
-        y = self.forward(x, residual)
+        y = self(x, residual)                     # through __call__: module hooks see the layer (output: the pair)
         return y if isinstance(y, tuple) else P.add_relu_fork(y, residual)
 
     def forward(self, x, _residual=None):

@@ -23,9 +23,9 @@ class PassportBlock(PassportLayerBase):
     def get_bias(self, force_passport=False):
         return super().get_bias(force_passport, 0)
 
-    def forward(self, x, force_passport=False):
-        return self._forward(x, force_passport, 0)
+    def forward(self, x, force_passport=False, _residual=None):
+        return self._forward(x, force_passport, 0, _residual)
 
     def forward_tail(self, x, residual, force_passport=False):
         """-> two handles of relu(self(x) + residual): this layer as the last one of a residual block."""
-        return self._forward(x, force_passport, 0, residual)
+        return self(x, force_passport, _residual=residual)
