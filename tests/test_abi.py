@@ -41,3 +41,26 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.HipLibraryMissing, match='no CPU or PyTorch fallback'):
         _lib.lib()
+
+
+def test_host_side_shape_queries_without_a_gpu():
+    """Planning functions that are pure host logic answer without a device; the ones that need the CU count say
+    'not resident' instead of failing."""
+    handle = _lib.lib()
+    # GroupNorm / InstanceNorm fused form: (N, C, HW, groups)
+    assert handle.deepipr_passport_gn_supported(128, 512, 16, 32) == 1       # ResNet layer4, GroupNorm(o // 16)
+    assert handle.deepipr_passport_gn_supported(128, 512, 16, 512) == 1      # InstanceNorm
+    assert handle.deepipr_passport_gn_supported(64, 64, 1024, 4) == 1        # 64 KB chunks: the largest that fit
+    assert handle.deepipr_passport_gn_supported(8, 64, 56 * 56, 4) == 0      # chunk beyond the register budget
+    assert handle.deepipr_passport_gn_supported(8, 64, 49, 4) == 0           # plane not a multiple of 4 floats
+    assert handle.deepipr_passport_gn_supported(8, 60, 16, 7) == 0           # groups do not divide the channels
+    assert handle.deepipr_passport_gn_workspace_bytes(128, 512, 16) == 128 * 2 * 512 * 8
+    # no device -> no CU count -> the single-pass BatchNorm form is never planned (callers then take 3 launches)
+    assert handle.deepipr_passport_bn_resident(128, 64, 1024, 1) in (0, 3)
+    assert handle.deepipr_passport_bn_resident(0, 64, 1024, 1) == 0
+    assert handle.deepipr_set_resident(2) == -1 and b'set_resident' in handle.deepipr_last_error()
+    assert handle.deepipr_set_resident(1) == 0
+    # entry points validate their arguments before touching the device
+    assert handle.deepipr_relu_bwd2(None, None, None, None, 16, None) == -1
+    assert handle.deepipr_passport_gn_fwd(None, None, None, None, None, None, 0.0, 0.1, 1e-5, 1, 1e-5, 1, 1, 4, 0, 1,
+                                          None, None, None, None, None, None, None, None) == -1
