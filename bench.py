@@ -73,6 +73,14 @@ def build_model(args, device):
     return model.to(device)
 
 
+def _exchange_timeouts():
+    try:
+        from deepipr_amd.passport_ops import kernels
+        return int(kernels.sync_timeouts())
+    except Exception:                                     # never let a diagnostic take the benchmark line down
+        return None
+
+
 def _numel(out):
     return (out[0] if isinstance(out, tuple) else out).numel()      # a block's last layer returns its output twice
 
@@ -333,6 +341,8 @@ def main():
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
+        # bounded in-kernel waits of the single-pass kernels' partial-sum exchange that ever expired (must be 0)
+        'exchange_timeouts': _exchange_timeouts(),
         'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '
                                 '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                 ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
