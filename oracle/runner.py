@@ -14,6 +14,7 @@ All of them expose the reference's module API (get_scale / get_bias / b / sign_l
 """
 import contextlib
 import io
+import random
 
 import numpy as np
 import torch
@@ -67,7 +68,7 @@ def fill(model, impl, case, salt=0):
 
 
 def case_inputs(case):
-    hw = 32
+    hw = case.get('hw', 32)
     x, y = patterns.batch(case['n'], 3, hw, hw, case['ncls'])
     wm = None
     if case.get('wm'):
@@ -95,9 +96,28 @@ def collect(case_name, impl, quiet=True):
         wm = (wm[0].to(dev), wm[1].to(dev))
 
     model.train()
-    with torch.no_grad():                       # materialise key_type='random' keys
-        model(x)
-    fill(model, impl, case)
+    sink = io.StringIO()
+    if case.get('key_type', 'random') == 'random':
+        with torch.no_grad():                   # materialise key_type='random' keys
+            model(x)
+        fill(model, impl, case)
+    else:
+        # --key-type shuffle (train_v1.py:30-31, experiments/classification.py:68-100): `nkeys` candidate images
+        # per key are pushed through a plain net and every passport layer keeps one passport picked from the
+        # activations that feed it (passport_generator.set_key -> set_intermediate_keys -> passport_selection,
+        # which draws from python's `random`).  Weights first: the keys are buffers the fill must not overwrite.
+        fill(model, impl, case)
+        plain = patterns.fill_state(impl.plain(case), salt=9)
+        hw = case.get('hw', 32)
+        kx, _ = patterns.batch(case['nkeys'], 3, hw, hw, case['ncls'], salt=2)
+        ky, _ = patterns.batch(case['nkeys'], 3, hw, hw, case['ncls'], salt=3)
+        random.seed(4321)
+        with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+            impl.set_keys(plain, model, kx.to(dev), ky.to(dev))
+        for name, m in model.named_modules():
+            if impl.is_passport(m):
+                out['key/' + name] = patterns.grad_digest(_np(m.key))
+                out['skey/' + name] = patterns.grad_digest(_np(m.skey))
 
     # per-layer gamma / beta / sign loss before the step
     with torch.no_grad():
@@ -121,7 +141,6 @@ def collect(case_name, impl, quiet=True):
     logits = []
     hook = model.register_forward_hook(lambda mod, inp, o: logits.append(_np(o)))
     opt = torch.optim.SGD(model.parameters(), **SGD)
-    sink = io.StringIO()
     with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
         res = impl.step(model, opt, (x, y), wm)
     hook.remove()

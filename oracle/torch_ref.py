@@ -5,6 +5,8 @@ fresh from the behaviour of the reference; every piece cites the lines it restat
 to /root/reference).  Module / parameter / buffer names equal the reference's so that
 oracle.patterns.fill_state() gives the reference, this oracle and the HIP build identical weights.
 """
+import random
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -95,7 +97,30 @@ class PassportLayerRef(nn.Module):
         self.use_relu = True if private else relu                                # private :66
         nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')  # :87-88
 
-    def set_key(self, x, y=None):                                                # :125-137 (n == 1 case)
+    @staticmethod
+    def passport_selection(cands):                                               # :90-123
+        """n candidates -> one passport: an RGB input keeps one whole image; otherwise output channel j is a
+        not-yet-taken channel of candidate j mod n, drawn (with redraws on collision) from python's `random`."""
+        n, c, h, w = cands.size()
+        if c == 3:
+            return cands[random.randint(0, n - 1)].unsqueeze(0)
+        flat = cands.view(n * c, h, w)
+        taken = [False] * (n * c)
+        chosen = []
+        for j in range(c):
+            src = j % n
+            idx = src * c + random.randint(0, c - 1)
+            while taken[idx]:
+                idx = src * c + random.randint(0, c - 1)
+            taken[idx] = True
+            chosen.append(flat[idx])
+        return torch.stack(chosen, dim=0).unsqueeze(0)
+
+    def set_key(self, x, y=None):                                                # :125-137
+        if int(x.size(0)) != 1:
+            x = self.passport_selection(x)
+            if y is not None:
+                y = self.passport_selection(y)
         self.register_buffer(self._k, x)
         self.register_buffer(self._sk, y)
 
@@ -161,6 +186,22 @@ class BasicBlockRef(nn.Module):
         if stride != 1 or in_planes != planes:
             self.shortcut = _make_block(kw['shortcut'], private)(in_planes, planes, 1, stride, 0)
 
+    def set_intermediate_keys(self, plain_block, x, y):                          # models/resnet_passport.py:32-65
+        """Each passport layer records what feeds it in the plain block; order convbnrelu_1, convbn_2, shortcut."""
+        if isinstance(self.convbnrelu_1, PassportLayerRef):
+            self.convbnrelu_1.set_key(x, y)
+        ox, oy = plain_block.convbnrelu_1(x), plain_block.convbnrelu_1(y)
+        if isinstance(self.convbn_2, PassportLayerRef):
+            self.convbn_2.set_key(ox, oy)
+        ox, oy = plain_block.convbn_2(ox), plain_block.convbn_2(oy)
+        if not isinstance(self.shortcut, nn.Sequential):
+            if isinstance(self.shortcut, PassportLayerRef):
+                self.shortcut.set_key(x, y)
+            ox, oy = ox + plain_block.shortcut(x), oy + plain_block.shortcut(y)
+        else:
+            ox, oy = ox + x, oy + y
+        return F.relu(ox), F.relu(oy)
+
     def forward(self, x, force_passport=False, ind=0):
         out = _call(self.convbnrelu_1, x, force_passport, ind)
         out = _call(self.convbn_2, out, force_passport, ind)
@@ -223,6 +264,15 @@ class ResNetRef(nn.Module):
             setattr(self, name, nn.Sequential(*blocks))
         self.linear = nn.Linear(512 * exp, num_classes)
 
+    def set_intermediate_keys(self, plain, x, y):                                # :145-161
+        with torch.no_grad():
+            if isinstance(self.convbnrelu_1, PassportLayerRef):                  # (a Sequential stem is skipped, :147)
+                self.convbnrelu_1.set_key(x, y)
+            x, y = plain.convbnrelu_1(x), plain.convbnrelu_1(y)
+            for name in ('layer1', 'layer2', 'layer3', 'layer4'):
+                for mine, theirs in zip(getattr(self, name), getattr(plain, name)):
+                    x, y = mine.set_intermediate_keys(theirs, x, y)
+
     def forward(self, x, force_passport=False, ind=0):                           # :163-180
         if isinstance(self.convbnrelu_1, nn.Sequential):
             out = self.convbnrelu_1[1](_call(self.convbnrelu_1[0], x, force_passport, ind))
@@ -271,10 +321,30 @@ class AlexNetRef(nn.Module):
         self.features = nn.Sequential(*layers)
         self.classifier = nn.Linear(4 * 4 * 256, num_classes)                     # :69
 
+    def set_intermediate_keys(self, plain, x, y):                                # :104-112
+        with torch.no_grad():
+            for theirs, mine in zip(plain.features, self.features):
+                if isinstance(mine, PassportLayerRef):
+                    mine.set_key(x, y)
+                x, y = theirs(x), theirs(y)
+
     def forward(self, x, force_passport=False, ind=0):                           # :114-122
         for m in self.features:
             x = _call(m, x, force_passport, ind)
         return self.classifier(x.view(x.size(0), -1))
+
+
+def plain_net(arch, num_classes, norm_type='bn'):
+    """The un-passported twin used to propagate keys (models/resnet_normal.py:9-27,52-71,126-127;
+    models/alexnet_normal.py:52-64): the same nets with every flag off -- identical module names."""
+    off = {'flag': False, 'norm_type': norm_type, 'key_type': 'random', 'sign_loss': 0}
+    if arch == 'alexnet':
+        return AlexNetRef(3, num_classes, {str(i): off for i in (0, 2, 4, 5, 6)})
+    blk = {'convbnrelu_1': off, 'convbn_2': off, 'shortcut': off}
+    kw = {'convbnrelu_1': off}
+    for li in (1, 2, 3, 4):
+        kw['layer%d' % li] = {'0': blk, '1': blk}
+    return resnet18_ref(num_classes=num_classes, passport_kwargs=kw)
 
 
 # ----------------------------------------------------------------------------- config -> kwargs

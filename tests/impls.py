@@ -17,11 +17,18 @@ class OracleImpl:
     device = torch.device('cpu')
 
     def build(self, case):
-        kw = torch_ref.passport_kwargs_from_config(case['config'], case['norm'], 'random', ALPHA)
+        kw = torch_ref.passport_kwargs_from_config(case['config'], case['norm'], case.get('key_type', 'random'),
+                                                   ALPHA)
         private = case['scheme'] != 1
         if case['arch'] == 'alexnet':
             return torch_ref.AlexNetRef(3, case['ncls'], kw, private=private)
         return torch_ref.resnet18_ref(num_classes=case['ncls'], passport_kwargs=kw, private=private)
+
+    def plain(self, case):
+        return torch_ref.plain_net(case['arch'], case['ncls'], case['norm'])
+
+    def set_keys(self, plain, model, kx, ky):
+        model.set_intermediate_keys(plain, kx, ky)
 
     def is_passport(self, m):
         return isinstance(m, torch_ref.PassportLayerRef)
@@ -56,7 +63,7 @@ class ProductImpl:
         from deepipr_amd.models.resnet_passport import ResNet18Passport
         from deepipr_amd.models.resnet_passport_private import ResNet18Private
         kw = construct_passport_kwargs_from_dict({'passport_config': case['config'], 'norm_type': case['norm'],
-                                                  'key_type': 'random', 'sl_ratio': ALPHA})
+                                                  'key_type': case.get('key_type', 'random'), 'sl_ratio': ALPHA})
         private = case['scheme'] != 1
         if case['arch'] == 'alexnet':
             model = (AlexNetPassportPrivate if private else AlexNetPassport)(3, case['ncls'], kw)
@@ -66,6 +73,17 @@ class ProductImpl:
             if self.is_passport(m):
                 m.fuse_norm = self.fuse_norm     # BatchNorm folded into the passport kernels, or the unfused ops
         return model.to(self.device)
+
+    def plain(self, case):
+        from deepipr_amd.models.alexnet_normal import AlexNetNormal
+        from deepipr_amd.models.resnet_normal import ResNet18
+        if case['arch'] == 'alexnet':
+            return AlexNetNormal(3, case['ncls'], case['norm']).to(self.device)
+        return ResNet18(num_classes=case['ncls'], norm_type=case['norm']).to(self.device)
+
+    def set_keys(self, plain, model, kx, ky):
+        from deepipr_amd import passport_generator
+        passport_generator.set_key(plain, model, kx, ky)
 
     def is_passport(self, m):
         from deepipr_amd.models._builders import PASSPORT_TYPES

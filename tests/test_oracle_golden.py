@@ -96,3 +96,48 @@ def test_numpy_layer_matches_reference_block(golden_dir):
         g2, b2 = npp.gamma_beta_fwd(W, pert if which == 0 else SK, pert if which == 1 else K, 2, 1)
         fd = ((g2 - gamma) @ dgamma + (b2 - beta) @ dbeta) / eps
         assert fd == pytest.approx(grad[idx], rel=1e-4, abs=1e-8)
+
+
+@pytest.mark.parametrize('name', ['bk3_s2', 'bn_s1', 'sc_1x1'])
+def test_dkey_matches_reference_autograd(name, golden_dir):
+    """d loss / d key, d skey: the reference's own autograd with the keys turned into nn.Parameters
+    (passport_attack_3.py:232-243; goldens blocks.npz: dkey/*) against (1) the oracle's stock-ATen layer and
+    (2) the numpy oracle's analytic dkey_of, which is what the HIP kernel is compared with on the GPU."""
+    from oracle import torch_ref
+    from oracle.cases import DKEY_GEOMETRIES, dkey_inputs
+    gold = load_golden(golden_dir, 'blocks')
+    ci, co, ks, s, pd, bk, hw, n, norm, relu = DKEY_GEOMETRIES[name]
+    t = {k: torch.from_numpy(v) for k, v in dkey_inputs(name).items()}
+    torch.manual_seed(0)
+    blk = torch_ref.PassportLayerRef(ci, co, ks, s, pd, {'norm_type': norm, 'key_type': 'random', 'sign_loss': 0.5},
+                                     relu=relu)
+    with torch.no_grad():
+        blk.weight.copy_(t['w'])
+        blk.b.copy_(t['b'])
+    del blk.key, blk.skey
+    blk.register_parameter('key', torch.nn.Parameter(t['key'].clone()))
+    blk.register_parameter('skey', torch.nn.Parameter(t['skey'].clone()))
+    blk.train()
+    x = t['x'].clone().requires_grad_(True)
+    # keep the gradients that reach gamma / beta: the inputs of the analytic d/dkey
+    grads = {}
+    orig_pooled = blk._pooled
+
+    def pooled(key):
+        r = orig_pooled(key)
+        r.register_hook(lambda g, which=('skey' if key is blk.skey else 'key'): grads.__setitem__(which, g.clone()))
+        return r
+    blk._pooled = pooled
+    y = blk(x)
+    ((y * t['cot']).sum() + blk.sign_loss.loss).backward()
+    pre = 'dkey/' + name + '/'
+    _close(y.detach().numpy(), gold[pre + 'y'], 'y')
+    _close(blk.key.grad.numpy(), gold[pre + 'dkey'], 'dkey (torch oracle)', rtol=1e-4, atol=1e-6)
+    _close(blk.skey.grad.numpy(), gold[pre + 'dskey'], 'dskey (torch oracle)', rtol=1e-4, atol=1e-6)
+    _close(blk.weight.grad.numpy(), gold[pre + 'dW'], 'dW', rtol=1e-4, atol=1e-5)
+    dgamma = grads['skey'].reshape(-1).double().numpy()
+    dbeta = grads['key'].reshape(-1).double().numpy()
+    _, dsk, dk = npp.gamma_beta_bwd(dgamma, dbeta, t['w'].double().numpy(), t['skey'].double().numpy(),
+                                    t['key'].double().numpy(), s, pd, need_dkey=True)
+    _close(dk, gold[pre + 'dkey'], 'dkey (numpy oracle)', rtol=1e-4, atol=1e-6)
+    _close(dsk, gold[pre + 'dskey'], 'dskey (numpy oracle)', rtol=1e-4, atol=1e-6)

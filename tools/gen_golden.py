@@ -31,6 +31,7 @@ sys.modules.setdefault('torchvision', _tv)
 sys.modules.setdefault('torchvision.models', _tvm)
 sys.path.insert(0, REF)
 
+import passport_generator                                            # noqa: E402
 from experiments.trainer import Trainer                              # noqa: E402
 from experiments.trainer_private import TesterPrivate, TrainerPrivate  # noqa: E402
 from experiments.utils import (construct_passport_kwargs_from_dict, load_normal_model_to_normal_model,  # noqa: E402
@@ -45,7 +46,8 @@ from models.resnet_passport import ResNet18Passport                  # noqa: E40
 from models.resnet_passport_private import ResNet18Private           # noqa: E402
 
 from oracle import runner                                            # noqa: E402
-from oracle.cases import ALPHA, CASES, alexnet_config, resnet18_config   # noqa: E402
+from oracle.cases import (ALPHA, CASES, DKEY_GEOMETRIES, alexnet_config, dkey_inputs,   # noqa: E402
+                          resnet18_config)
 
 
 class ReferenceImpl:
@@ -54,13 +56,22 @@ class ReferenceImpl:
     def build(self, case):
         kw = construct_passport_kwargs_from_dict({'passport_config': case['config'],
                                                   'norm_type': case['norm'],
-                                                  'key_type': 'random', 'sl_ratio': ALPHA})
+                                                  'key_type': case.get('key_type', 'random'), 'sl_ratio': ALPHA})
         private = case['scheme'] != 1
         if case['arch'] == 'alexnet':
             cls = AlexNetPassportPrivate if private else AlexNetPassport
             return cls(3, case['ncls'], kw)
         cls = ResNet18Private if private else ResNet18Passport
         return cls(num_classes=case['ncls'], passport_kwargs=kw)
+
+    def plain(self, case):
+        """The key-propagation net of --key-type shuffle (experiments/classification.py:68-100)."""
+        if case['arch'] == 'alexnet':
+            return AlexNetNormal(3, case['ncls'], case['norm'])
+        return ResNet18(num_classes=case['ncls'], norm_type=case['norm'])
+
+    def set_keys(self, plain, model, kx, ky):
+        passport_generator.set_key(plain, model, kx, ky)
 
     def is_passport(self, m):
         return isinstance(m, (PassportBlock, PassportPrivateBlock))
@@ -195,6 +206,38 @@ def block_cases():
     blk.set_key(cands, cands + 1000)
     out['selection/set_key_key'] = blk.key.numpy().copy()
     out['selection/set_key_skey'] = blk.skey.numpy().copy()
+    out.update(dkey_cases())
+    return out
+
+
+def dkey_cases():
+    """d loss / d key and d skey from the reference's OWN autograd, keys turned into nn.Parameters the way
+    passport_attack_3.py:232-243 does (delattr the buffer, register_parameter under the same name)."""
+    out = {}
+    for name, (ci, co, ks, s, pd, bk, hw, n, norm, relu) in DKEY_GEOMETRIES.items():
+        t = {k: torch.from_numpy(v) for k, v in dkey_inputs(name).items()}
+        torch.manual_seed(0)
+        blk = PassportBlock(ci, co, ks, s, pd, {'norm_type': norm, 'key_type': 'random', 'sign_loss': 0.5},
+                            relu=relu)
+        with torch.no_grad():
+            blk.weight.copy_(t['w'])
+            blk.b.copy_(t['b'])
+        blk.__delattr__('key')
+        blk.__delattr__('skey')
+        blk.register_parameter('key', torch.nn.Parameter(t['key'].clone()))
+        blk.register_parameter('skey', torch.nn.Parameter(t['skey'].clone()))
+        blk.train()
+        x = t['x'].clone().requires_grad_(True)
+        y = blk(x)
+        ((y * t['cot']).sum() + blk.sign_loss.loss).backward()
+        pre = 'dkey/' + name + '/'
+        out[pre + 'y'] = y.detach().numpy()
+        out[pre + 'gamma'] = blk.sign_loss.scale_cache.detach().numpy().reshape(-1)
+        out[pre + 'sign_loss'] = np.float64(blk.sign_loss.loss.item())
+        out[pre + 'dkey'] = blk.key.grad.numpy().copy()
+        out[pre + 'dskey'] = blk.skey.grad.numpy().copy()
+        out[pre + 'dW'] = blk.weight.grad.numpy().copy()
+        out[pre + 'dx'] = x.grad.numpy().copy()
     return out
 
 
