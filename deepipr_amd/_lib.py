@@ -29,6 +29,7 @@ SIGNATURES = {
     'deepipr_pooled_patch_mean': (_int, [_f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f64p, _vp]),
     'deepipr_gamma_beta_fwd': (_int, [_f32p, _f64p, _int, _int, _f32p, _f32p, _vp]),
     'deepipr_gamma_beta_bwd': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
+    'deepipr_gamma_beta_bwd_acc': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
     'deepipr_gamma_beta_dkey_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_gamma_beta_dkey': (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _f32p, _vp, _vp]),
@@ -47,6 +48,8 @@ SIGNATURES = {
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd2': (_int, [_f32p, _f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
+    'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
+    'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
                                        _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,
@@ -65,7 +68,7 @@ SIGNATURES = {
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 SYNC_WORDS = 4096 + 16           # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 4096        # DEEPIPR_SYNC_TIMEOUT_WORD
 
@@ -114,6 +117,11 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd']
+
+
+def debug_tune(key, value):
+    """Tuning / test knobs of the single-pass kernels (include/deepipr_hip.h: deepipr_debug_tune)."""
+    check(lib().deepipr_debug_tune(key.encode(), int(value)), 'debug_tune')
 
 
 def set_resident(on):

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/deepipr_hip.h"
@@ -269,7 +270,9 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta(
 
 // Rank-2 update rows: dW[co0+r, :] = dg[r] * m_scale + db[r] * m_bias (pooled means rounded to f32),
 // the pooled vectors loaded once for the RPW rows.
-template <bool VEC, int RPW>
+// ACC: dW already holds the data convolution's wgrad; the rank-2 update is added to it in place (8 B per weight
+// instead of a fresh 4 B write + autograd's 12 B add kernel).
+template <bool VEC, int RPW, bool ACC = false>
 __device__ __forceinline__ void write_dw_rows(float *__restrict__ dW, const double *__restrict__ s, int Co,
                                               int K, int co0, const float *dg, const float *db) {
     const double *ss = s, *sb = s + K;
@@ -291,7 +294,12 @@ __device__ __forceinline__ void write_dw_rows(float *__restrict__ dW, const doub
                 o.y = fmaf(dg[r], ms.y, db[r] * mb.y);
                 o.z = fmaf(dg[r], ms.z, db[r] * mb.z);
                 o.w = fmaf(dg[r], ms.w, db[r] * mb.w);
-                reinterpret_cast<float4 *>(dW + static_cast<size_t>(co0 + r) * K)[q] = o;
+                float4 *dst = reinterpret_cast<float4 *>(dW + static_cast<size_t>(co0 + r) * K) + q;
+                if (ACC) {
+                    const float4 w = *dst;
+                    o = make_float4(w.x + o.x, w.y + o.y, w.z + o.z, w.w + o.w);
+                }
+                *dst = o;
             }
         }
     } else {
@@ -300,13 +308,15 @@ __device__ __forceinline__ void write_dw_rows(float *__restrict__ dW, const doub
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 if (co0 + r >= Co) break;
-                dW[static_cast<size_t>(co0 + r) * K + k] = fmaf(dg[r], ms, db[r] * mb);
+                float *dst = dW + static_cast<size_t>(co0 + r) * K + k;
+                const float o = fmaf(dg[r], ms, db[r] * mb);
+                *dst = ACC ? *dst + o : o;
             }
         }
     }
 }
 
-template <bool VEC, int RPW>
+template <bool VEC, int RPW, bool ACC>
 __global__ __launch_bounds__(kThreads) void k_gamma_beta_bwd(
     const float *__restrict__ dgamma, const float *__restrict__ dbeta, const double *__restrict__ s,
     int Co, int K, float *__restrict__ dW) {
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta_bwd(
         dg[r] = dgamma[co];
         db[r] = dbeta[co];
     }
-    write_dw_rows<VEC, RPW>(dW, s, Co, K, co0, dg, db);
+    write_dw_rows<VEC, RPW, ACC>(dW, s, Co, K, co0, dg, db);
 }
 
 // ============================================================================================
@@ -797,7 +807,12 @@ constexpr int kTbl = 8;
 enum WalkMode { WALK_STATS = 1, WALK_BN_BWD = 2 };
 
 struct BnFinishArgs {
-    const double *part;        // [NS][2][C] sums of x and x^2 (training) or nullptr (use running stats)
+    const double *part;        // [NS][2][C] sums of (x-K) and (x-K)^2 (training) or nullptr (use running stats)
+    // The sums are SHIFTED by K[c] = x[0][c][0] (the channel's first element, any sample of the distribution):
+    // var = E[(x-K)^2] - E[x-K]^2 has no catastrophic cancellation when |mean| >> std, unlike E[x^2] - mean^2 on
+    // fp32 partials (ATen gets the same robustness from Welford updates).
+    const float *shift_src;    // x; K[c] = shift_src[c * HW]
+    int HW;
     int NS;
     double inv_m;              // 1 / (N*HW)
     double unbias;             // M / (M-1)
@@ -819,9 +834,10 @@ __device__ __forceinline__ void bn_finish_channel(const BnFinishArgs &f, int C, 
         }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
-        const double mu = s1 * f.inv_m;
-        double var = s2 * f.inv_m - mu * mu;           // biased variance, f64
+        const double dmu = s1 * f.inv_m;               // mean - K
+        double var = s2 * f.inv_m - dmu * dmu;         // biased variance, f64, from the shifted sums
         if (var < 0.0) var = 0.0;
+        const double mu = static_cast<double>(f.shift_src[static_cast<size_t>(c) * f.HW]) + dmu;
         mean = static_cast<float>(mu);
         invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
         if (lane == 0 && f.running_mean) {
@@ -877,9 +893,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_table(const float *__restrict__
 template <int MODE, bool RELU>
 __device__ __forceinline__ void walk_accum(float d, float x, float mean, float invstd, float g, float bt,
                                            float &a0, float &a1) {
-    if (MODE == WALK_STATS) {
-        a0 += x;
-        a1 = fmaf(x, x, a1);
+    if (MODE == WALK_STATS) {                      // `mean` carries the channel's shift K here
+        const float xs = x - mean;
+        a0 += xs;
+        a1 = fmaf(xs, xs, a1);
     } else {
         const float xh = (x - mean) * invstd;
         float dz = d;
@@ -917,6 +934,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_walk_small(
             istd[i] = c4.y;
             g[i] = c4.z;
             bt[i] = c4.w;
+        } else {
+            mean[i] = xin[static_cast<size_t>(c0 + cc) * P];          // shift K[c] = x[0][c][0]
         }
     }
     if (lane_on) {
@@ -1002,6 +1021,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_walk_large(
         istd = c4.y;
         g = c4.z;
         bt = c4.w;
+    } else {
+        mean = xin[static_cast<size_t>(c) * P];                       // shift K[c] = x[0][c][0]
     }
     double A0 = 0.0, A1 = 0.0;
     const int n0 = blockIdx.y * pl.ips, n1 = min(N, n0 + pl.ips);
@@ -1306,6 +1327,10 @@ struct ResPlan {
     int G, q4, gq;        // channels per workgroup, float4 per plane, G*q4
     int blocks;           // (C/G) * S
     FastDiv gqdiv;
+    unsigned spin;        // bound of the exchange wait (kSpinLimit; tests shorten it)
+    int drop;             // test hook: this slice never posts its ticket (-1 = none)
+    int stagger;          // s_sleep(4) rounds the second cohort of workgroups waits before loading (2 per CU)
+    int cohort;           // workgroups below this index are the first cohort
 };
 
 __device__ __forceinline__ void sc1_store(double *p, double v) {
@@ -1353,29 +1378,51 @@ __device__ __forceinline__ void res_block_sums(double &a, double &b, const ResPl
 }
 
 // In-launch exchange of one channel's two partial sums between its S slice workgroups (thread 0 only).
+// Hand-off form (MI355X_MICROARCH.md, "valid forms"): write-through (sc1) payload stores -> s_waitcnt vmcnt(0)
+// (inline asm: the compiler cannot drop it) -> agent-scope ticket; the reader polls the ticket with sc1 loads (they
+// bypass this CU's L1), then reads the payload with sc1 loads -- which may replace an agent acquire because the
+// producer stored sc1.  The compiler barriers keep the payload loads behind the poll in program order; the
+// hardware returns vector loads of one wave in order.
+// A wait that expires does NOT carry on with whatever the workspace holds: the statistics are poisoned with NaN
+// (every output of the layer, hence the loss, becomes NaN) and sync[kSyncTimeoutWord] is raised for the host.
 __device__ __forceinline__ void res_exchange(double &s0, double &s1, double *part, int C, int c, int s, int S,
-                                             unsigned *sync, int cb) {
+                                             unsigned *sync, int cb, unsigned spin_limit, int drop) {
     sc1_store(part + (static_cast<size_t>(s) * 2 + 0) * C + c, s0);
     sc1_store(part + (static_cast<size_t>(s) * 2 + 1) * C + c, s1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(sync + cb, 64u / static_cast<unsigned>(S), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
+    unsigned ticket;
+    if (s == drop)                                     // test hook: a partner that never arrives
+        ticket = __hip_atomic_load(sync + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        ticket = __hip_atomic_fetch_add(sync + cb, 64u / static_cast<unsigned>(S), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);     // relaxed: the payload is already written through
     const unsigned target = (ticket & ~63u) + 64u;
     unsigned spins = 0;
+    bool expired = false;
     while (static_cast<int>(__hip_atomic_load(sync + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > kSpinLimit) {
+        if (++spins > spin_limit) {
             __hip_atomic_store(sync + kSyncTimeoutWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            expired = true;
             break;
         }
     }
+    asm volatile("" ::: "memory");                     // payload loads stay behind the poll
     double t0 = 0.0, t1 = 0.0;
     for (int sp = 0; sp < S; ++sp) {
         t0 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 0) * C + c);
         t1 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 1) * C + c);
     }
+    if (expired) t0 = t1 = __longlong_as_double(0x7ff8000000000000LL);
     s0 = t0;
     s1 = t1;
+}
+
+// Second cohort of workgroups (two per CU): wait `rounds` x s_sleep(4) before issuing loads, so that its read phase
+// follows the first cohort's and each cohort's reduce/exchange bubble is covered by the other's memory phase.
+__device__ __forceinline__ void res_stagger(const ResPlan &pl) {
+    if (pl.stagger > 0 && static_cast<int>(blockIdx.x) >= pl.cohort)
+        for (int i = 0; i < pl.stagger; ++i) __builtin_amdgcn_s_sleep(4);
 }
 
 template <int T>
@@ -1409,7 +1456,7 @@ __device__ __forceinline__ void sign_loss_block_t(const float *__restrict__ gamm
 }
 
 template <int T, int F4>
-__global__ __launch_bounds__(T) void k_bn_res_fwd(
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
     const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
     const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
     unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
@@ -1427,12 +1474,15 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
+    // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
+    res_stagger(pl);
+    const float K = reinterpret_cast<const float *>(x)[static_cast<size_t>(c0 + c_local) * pl.q4 * 4];
     float4 v[F4];
     unsigned idx[F4];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
-        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        v[k] = make_float4(K, K, K, K);                                // unused units contribute (K-K) = 0
         idx[k] = 0;
         if (j < units) {
             const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
@@ -1443,17 +1493,18 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
-        a0 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        a1 = fmaf(v[k].x, v[k].x, a1);
-        a1 = fmaf(v[k].y, v[k].y, a1);
-        a1 = fmaf(v[k].z, v[k].z, a1);
-        a1 = fmaf(v[k].w, v[k].w, a1);
+        const float dx0 = v[k].x - K, dx1 = v[k].y - K, dx2 = v[k].z - K, dx3 = v[k].w - K;
+        a0 += (dx0 + dx1) + (dx2 + dx3);
+        a1 = fmaf(dx0, dx0, a1);
+        a1 = fmaf(dx1, dx1, a1);
+        a1 = fmaf(dx2, dx2, a1);
+        a1 = fmaf(dx3, dx3, a1);
     }
     double s1 = static_cast<double>(a0), s2 = static_cast<double>(a1);
     res_block_sums<T>(s1, s2, pl, c_local, red);
     if (pl.S > 1) {                                   // G == 1 here
         if (t == 0) {
-            res_exchange(s1, s2, part, C, c0, s, pl.S, sync, cb);
+            res_exchange(s1, s2, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
             xch[0] = s1;
             xch[1] = s2;
         }
@@ -1463,10 +1514,10 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     }
     if (t < pl.gq && t == c_local * pl.q4) {          // one thread per local channel
         const int c = c0 + c_local;
-        const double mu = s1 * f.inv_m;
-        double var = s2 * f.inv_m - mu * mu;
+        const double dmu = s1 * f.inv_m;                               // mean - K
+        double var = s2 * f.inv_m - dmu * dmu;
         if (var < 0.0) var = 0.0;
-        const float mean = static_cast<float>(mu);
+        const float mean = static_cast<float>(static_cast<double>(K) + dmu);
         const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
         const float g = gamma[c], bt = beta[c];
         chan[c_local] = make_float4(mean, invstd, g, bt);
@@ -1525,7 +1576,7 @@ __device__ __forceinline__ void res_bwd_prep(float d, float xv, const float4 &ch
 }
 
 template <int T, int F4>
-__global__ __launch_bounds__(T) void k_bn_res_bwd(
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
     const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
     float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, double *part, unsigned *sync, ResBwdArgs a) {
     constexpr int NW = T / kWave;
@@ -1537,6 +1588,7 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    res_stagger(pl);
     const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
     float4 dz[F4], xh[F4];
     unsigned idx[F4];
@@ -1583,7 +1635,7 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
     res_block_sums<T>(ag, ab, pl, c_local, red);
     if (pl.S > 1) {
         if (t == 0) {
-            res_exchange(ag, ab, part, C, c0, s, pl.S, sync, cb);
+            res_exchange(ag, ab, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
             xch[0] = ag;
             xch[1] = ab;
         }
@@ -1666,29 +1718,32 @@ __global__ void k_gn_fwd(const float4 *__restrict__ x, float4 *__restrict__ y, c
     const int lane = t & (pl.TG - 1);
     const bool on = chunk < pl.chunks;
     const size_t base = static_cast<size_t>(on ? chunk : 0) * pl.U;
+    // shifted sums (see BnFinishArgs): K = the chunk's first element
+    const float K = reinterpret_cast<const float *>(x + base)[0];
     float4 v[F4];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
         const int u = lane + k * pl.TG;
-        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        v[k] = make_float4(K, K, K, K);
         if (on && u < pl.U) v[k] = x[base + u];
     }
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
-        a0 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        a1 = fmaf(v[k].x, v[k].x, a1);
-        a1 = fmaf(v[k].y, v[k].y, a1);
-        a1 = fmaf(v[k].z, v[k].z, a1);
-        a1 = fmaf(v[k].w, v[k].w, a1);
+        const float dx0 = v[k].x - K, dx1 = v[k].y - K, dx2 = v[k].z - K, dx3 = v[k].w - K;
+        a0 += (dx0 + dx1) + (dx2 + dx3);
+        a1 = fmaf(dx0, dx0, a1);
+        a1 = fmaf(dx1, dx1, a1);
+        a1 = fmaf(dx2, dx2, a1);
+        a1 = fmaf(dx3, dx3, a1);
     }
     double s1 = static_cast<double>(a0), s2 = static_cast<double>(a1);
     gn_group_sums(s1, s2, pl.TG, red);
     const double inv_m = 1.0 / (static_cast<double>(pl.U) * 4.0);
-    const double mu = s1 * inv_m;
-    double var = s2 * inv_m - mu * mu;
+    const double dmu = s1 * inv_m;
+    double var = s2 * inv_m - dmu * dmu;
     if (var < 0.0) var = 0.0;
-    const float mean = static_cast<float>(mu);
+    const float mean = static_cast<float>(static_cast<double>(K) + dmu);
     const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
     if (on && lane == 0) *reinterpret_cast<float2 *>(stats + static_cast<size_t>(chunk) * 2) = make_float2(mean, invstd);
     const int c0 = (on ? chunk % pl.groups : 0) * pl.cpg;
@@ -1817,9 +1872,19 @@ __global__ void k_gn_bwd(const float4 *__restrict__ dy, const float4 *__restrict
 // One streaming pass: reads p, g, buf and writes p, buf = 20 B per parameter.  `grad_scale` folds the
 // 1/world_size of a summed all-reduce into the same pass.
 // ============================================================================================
+// `hp` != nullptr: {lr, momentum, weight decay, grad scale} are read from device memory instead of the launch
+// arguments, so a step captured in a hipGraph follows a learning-rate schedule (the host rewrites the four floats
+// between replays; launch arguments are frozen at capture time).
 __global__ __launch_bounds__(kThreads) void k_sgd_momentum_v4(float4 *__restrict__ p, const float4 *__restrict__ g,
                                                               float4 *__restrict__ buf, size_t n4, float lr,
-                                                              float mu, float wd, float gs) {
+                                                              float mu, float wd, float gs,
+                                                              const float *__restrict__ hp) {
+    if (hp) {
+        lr = hp[0];
+        mu = hp[1];
+        wd = hp[2];
+        gs = hp[3];
+    }
     const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += step) {
         float4 pv = p[i], bv = buf[i];
@@ -1836,7 +1901,13 @@ __global__ __launch_bounds__(kThreads) void k_sgd_momentum_v4(float4 *__restrict
 
 __global__ __launch_bounds__(kThreads) void k_sgd_momentum_s(float *__restrict__ p, const float *__restrict__ g,
                                                              float *__restrict__ buf, size_t n, float lr, float mu,
-                                                             float wd, float gs) {
+                                                             float wd, float gs, const float *__restrict__ hp) {
+    if (hp) {
+        lr = hp[0];
+        mu = hp[1];
+        wd = hp[2];
+        gs = hp[3];
+    }
     const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += step) {
         const float d = fmaf(wd, p[i], gs * g[i]);
@@ -2097,22 +2168,41 @@ int deepipr_gamma_beta_fwd(const float *W, const double *s, int Co, int K, float
     return check_launch("gamma_beta_fwd");
 }
 
+}  // extern "C"
+
+namespace {
+template <bool ACC>
+int launch_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double *s, int Co, int K, float *dW,
+                          hipStream_t st) {
+    ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
+    prof.bytes = (ACC ? 8.0 : 4.0) * static_cast<double>(Co) * K;
+    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
+    if (Co >= 2 * kRowPairMinCo) {
+        const dim3 grid((Co + 1) / 2);
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 2, ACC>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 2, ACC>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+    } else {
+        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 1, ACC>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 1, ACC>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+    }
+    return check_launch(ACC ? "gamma_beta_bwd_acc" : "gamma_beta_bwd");
+}
+}  // namespace
+
+extern "C" {
+
 int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double *s, int Co, int K,
                            float *dW, void *stream) {
     if (!dgamma || !dbeta || !s || !dW || Co <= 0 || K <= 0)
         return fail(DEEPIPR_EINVAL, "gamma_beta_bwd: bad argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
-    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
-    if (Co >= 2 * kRowPairMinCo) {
-        const dim3 grid((Co + 1) / 2);
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 2>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 2>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-    } else {
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 1>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 1>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-    }
-    return check_launch("gamma_beta_bwd");
+    return launch_gamma_beta_bwd<false>(dgamma, dbeta, s, Co, K, dW, static_cast<hipStream_t>(stream));
+}
+
+int deepipr_gamma_beta_bwd_acc(const float *dgamma, const float *dbeta, const double *s, int Co, int K,
+                               float *dW, void *stream) {
+    if (!dgamma || !dbeta || !s || !dW || Co <= 0 || K <= 0)
+        return fail(DEEPIPR_EINVAL, "gamma_beta_bwd_acc: bad argument");
+    return launch_gamma_beta_bwd<true>(dgamma, dbeta, s, Co, K, dW, static_cast<hipStream_t>(stream));
 }
 
 size_t deepipr_gamma_beta_dkey_workspace_bytes(int Ci, int kh, int kw) {
@@ -2278,11 +2368,24 @@ int device_cu_count() {
     return cache[dev] > 0 ? cache[dev] : 0;
 }
 
-// Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread of a 1024-thread workgroup may keep.
+// Tuning / test knobs of the single-pass kernels (deepipr_debug_tune); defaults are the shipped configuration.
+struct ResTune {
+    std::atomic<int> wg2{0};          // 1: plan two 512-thread workgroups per CU instead of one of 1024
+    std::atomic<int> stagger{0};      // s_sleep(4) rounds the second cohort waits before its loads (wg2 only)
+    std::atomic<int> split_full{0};   // 1: split channels over slices whenever they do not fill the chip (not just < half)
+    std::atomic<int> spin{static_cast<int>(kSpinLimit)};
+    std::atomic<int> drop{-1};        // test hook: slice that never posts its exchange ticket
+};
+ResTune g_tune;
+
+// Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread may keep at 4 waves per SIMD.
 bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out) {
     if (g_resident_mode.load(std::memory_order_relaxed) == 0 || P % 4 != 0) return false;
     const int cus = device_cu_count();
     if (cus <= 0) return false;
+    const int per_cu = g_tune.wg2.load(std::memory_order_relaxed) ? 2 : 1;
+    const int cap = cus * per_cu;                                   // workgroups that are co-resident for certain
+    const bool split_full = g_tune.split_full.load(std::memory_order_relaxed) != 0;
     ResPlan pl{};
     pl.q4 = P / 4;
     int G = 1;
@@ -2290,10 +2393,10 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         G = 8 / pl.q4;
         while (G > 1 && C % G != 0) G >>= 1;
     }
-    auto slices = [&](int cb) {                  // split channels only when they cover less than half the CUs:
+    auto slices = [&](int cb) {                  // split channels only when they cover less than half the slots:
         int S = 1;                               // 128 workgroups already stream as fast as 256 with the exchange
-        if (can_sync && cb * 2 < cus)
-            while (S < 64 && cb * (S * 2) <= cus && S * 2 <= N) S *= 2;
+        if (can_sync && (split_full ? cb < cap : cb * 2 < cap))
+            while (S < 64 && cb * (S * 2) <= cap && S * 2 <= N) S *= 2;
         return S;
     };
     int S = slices(C / G);
@@ -2308,18 +2411,27 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     pl.nps = (N + S - 1) / S;
     pl.blocks = (C / G) * S;
     const long long units = static_cast<long long>(pl.nps) * pl.gq;
-    pl.T = (S == 1 && units <= 8 * 256) ? 256 : 1024;
+    const int big_t = per_cu == 2 ? 512 : 1024;
+    pl.T = (S == 1 && units <= 8 * 256) ? 256 : big_t;
     if (pl.blocks * 4 < cus) return false;                   // too few workgroups to be worth a single pass
-    const long long need = (units + pl.T - 1) / pl.T;
     static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    pl.F4 = 0;
-    for (int f : steps)
-        if (f >= need && f <= (pl.T == 256 ? 8 : max_f4)) {
-            pl.F4 = f;
-            break;
-        }
+    auto pick = [&](int T) {
+        const long long need = (units + T - 1) / T;
+        for (int f : steps)
+            if (f >= need && f <= (T == 256 ? 8 : max_f4)) return f;
+        return 0;
+    };
+    pl.F4 = pick(pl.T);
+    if (pl.F4 == 0 && pl.T == 512 && S == 1) {               // no exchange, no residency constraint: one big workgroup
+        pl.T = 1024;
+        pl.F4 = pick(1024);
+    }
     if (pl.F4 == 0) return false;
     pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
+    pl.spin = static_cast<unsigned>(g_tune.spin.load(std::memory_order_relaxed));
+    pl.drop = g_tune.drop.load(std::memory_order_relaxed);
+    pl.stagger = (per_cu == 2 && pl.blocks > cus) ? g_tune.stagger.load(std::memory_order_relaxed) : 0;
+    pl.cohort = cus;
     *out = pl;
     return true;
 }
@@ -2346,6 +2458,12 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
     const int ws = with_sign ? 1 : 0;
     if (pl.T == 256) {
         DEEPIPR_RES_CASES(k_bn_res_fwd, 256, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
+    } else if (pl.T == 512 && pl.F4 == 12) {
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<512, 12>), grid, dim3(512), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
+    } else if (pl.T == 512 && pl.F4 == 16) {
+        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<512, 16>), grid, dim3(512), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
+    } else if (pl.T == 512) {
+        DEEPIPR_RES_CASES(k_bn_res_fwd, 512, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
     } else if (pl.F4 == 12) {
         DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
     } else if (pl.F4 == 16) {
@@ -2365,6 +2483,8 @@ int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx,
     float4 *o4 = reinterpret_cast<float4 *>(dx);
     if (pl.T == 256) {
         DEEPIPR_RES_CASES(k_bn_res_bwd, 256, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
+    } else if (pl.T == 512) {
+        DEEPIPR_RES_CASES(k_bn_res_bwd, 512, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
     } else {
         DEEPIPR_RES_CASES(k_bn_res_bwd, 1024, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
     }
@@ -2427,6 +2547,18 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
     return mask;
 }
 
+int deepipr_debug_tune(const char *key, int value) {
+    if (!key) return fail(DEEPIPR_EINVAL, "debug_tune: null key");
+    const std::string k(key);
+    if (k == "wg2") g_tune.wg2.store(value != 0);
+    else if (k == "stagger") g_tune.stagger.store(value < 0 ? 0 : value);
+    else if (k == "split_full") g_tune.split_full.store(value != 0);
+    else if (k == "exchange_spin") g_tune.spin.store(value <= 0 ? static_cast<int>(kSpinLimit) : value);
+    else if (k == "exchange_drop") g_tune.drop.store(value);
+    else return fail(DEEPIPR_EINVAL, "debug_tune: unknown key '%s'", key);
+    return DEEPIPR_OK;
+}
+
 int deepipr_set_resident(int mode) {
     if (mode != 0 && mode != 1) return fail(DEEPIPR_EINVAL, "set_resident: mode must be 0 or 1");
     g_resident_mode.store(mode);
@@ -2465,6 +2597,8 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
     f.running_var = running_var;
     f.num_batches_tracked = num_batches_tracked;
     f.tbl = table;
+    f.shift_src = x;
+    f.HW = HW;
     ResPlan rp;
     if (training && aligned16(x) && aligned16(y) && plan_resident(N, C, HW, 16, sync != nullptr, &rp)) {
         // single pass: x stays in registers between the statistics and the normalise/affine/ReLU phase
@@ -2743,22 +2877,40 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
 }
 
 
-int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
-                              float momentum, float weight_decay, float grad_scale, void *stream) {
-    if (!param || !grad || !momentum_buf || n == 0) return fail(DEEPIPR_EINVAL, "sgd_momentum_step: bad argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+}  // extern "C"
+
+namespace {
+int launch_sgd(float *param, const float *grad, float *momentum_buf, size_t n, float lr, float momentum,
+               float weight_decay, float grad_scale, const float *hyper, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_SGD, st);
     prof.bytes = 20.0 * static_cast<double>(n);
     if (n % 4 == 0 && aligned16(param) && aligned16(grad) && aligned16(momentum_buf)) {
         const size_t n4 = n / 4;
         DEEPIPR_LAUNCH(prof, k_sgd_momentum_v4, dim3(grid_for(n4)), dim3(kThreads), st, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(momentum_buf), n4, lr,
-                       momentum, weight_decay, grad_scale);
+                       momentum, weight_decay, grad_scale, hyper);
     } else {
         DEEPIPR_LAUNCH(prof, k_sgd_momentum_s, dim3(grid_for(n)), dim3(kThreads), st, param, grad, momentum_buf, n, lr,
-                       momentum, weight_decay, grad_scale);
+                       momentum, weight_decay, grad_scale, hyper);
     }
     return check_launch("sgd_momentum_step");
+}
+}  // namespace
+
+extern "C" {
+
+int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
+                              float momentum, float weight_decay, float grad_scale, void *stream) {
+    if (!param || !grad || !momentum_buf || n == 0) return fail(DEEPIPR_EINVAL, "sgd_momentum_step: bad argument");
+    return launch_sgd(param, grad, momentum_buf, n, lr, momentum, weight_decay, grad_scale, nullptr,
+                      static_cast<hipStream_t>(stream));
+}
+
+int deepipr_sgd_momentum_step_dev(float *param, const float *grad, float *momentum_buf, size_t n,
+                                  const float *hyper, void *stream) {
+    if (!param || !grad || !momentum_buf || !hyper || n == 0)
+        return fail(DEEPIPR_EINVAL, "sgd_momentum_step_dev: bad argument");
+    return launch_sgd(param, grad, momentum_buf, n, 0.0f, 0.0f, 0.0f, 1.0f, hyper, static_cast<hipStream_t>(stream));
 }
 
 

@@ -32,36 +32,63 @@ class GraphedTrainStep:
     optimizer_in_graph=False (data parallel): zero_grad -> forward -> losses -> backward are captured; after each
         replay optimizer.step() runs eagerly -- with FlatSGD that is: pack the (static-address) gradients bucket by
         bucket, all-reduce them over RCCL, one fused SGD kernel.  No collective is ever captured, so the graph
-        contains only this process's own kernels."""
+        contains only this process's own kernels.
+
+    Learning-rate schedules.  Launch arguments are frozen at capture time, so a captured optimiser would keep the
+    learning rate it was captured with while MultiStepLR (lr_configs/*.json: decay at epochs 100 and 150) moves
+    param_groups on.  Two mechanisms keep a replayed step on the schedule:
+      * FlatSGD reads {lr, momentum, weight decay, 1/world} from device memory; `sync_hyper()` refreshes those four
+        floats before a replay whenever param_groups changed -- no re-capture;
+      * any other optimiser: the hyper-parameters of every param group are compared with the captured ones before
+        each replay and the step is re-captured when they differ (a few times per training run)."""
 
     def __init__(self, step_fn, model, optimizer, data, target, warmup=3, optimizer_in_graph=True):
         self.static_data = data.clone()
         self.static_target = target.clone()
+        self.step_fn, self.model = step_fn, model
         self.optimizer = optimizer
         self.optimizer_in_graph = optimizer_in_graph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up off the capture stream: MIOpen find,
+        self.recaptures = 0
+        # warm-up and capture share ONE side stream: everything the kernels keep per (device, stream) -- scratch
+        # arena, in-launch exchange words -- is created by the eager warm-up, never inside the capture (a captured
+        # zero-fill of the exchange words would be replayed every step and erase their time-out flag)
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):               # warm-up off the caller's stream: MIOpen find,
             for _ in range(warmup):                        # allocator pools, lazily created optimizer state
                 step_fn(model, optimizer, self.static_data, self.static_target)
             if warmup == 0:
                 # training must not advance, but MIOpen still has to pick its algorithms and SGD has to create
                 # its momentum buffers outside the capture: run one step on throw-away copies of the state
                 self._dry_run(step_fn, model, optimizer)
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self._capture()
+
+    def _hyper_signature(self):
+        return tuple(tuple((k, v) for k, v in sorted(g.items()) if k != 'params' and isinstance(v, (int, float, bool)))
+                     for g in self.optimizer.param_groups)
+
+    def _capture(self):
+        from deepipr_amd import passport_ops
+        optimizer = self.optimizer
         optimizer.zero_grad(set_to_none=True)
+        passport_ops.kernels.prepare_stream(self.static_data.device, self.stream)
+        self._device_hyper = hasattr(optimizer, 'sync_hyper')
+        if self._device_hyper:
+            optimizer.sync_hyper()
+        self._captured_hyper = self._hyper_signature()
         self.graph = torch.cuda.CUDAGraph()
-        captured_opt = optimizer if optimizer_in_graph else _NoStep(optimizer)
+        captured_opt = optimizer if self.optimizer_in_graph else _NoStep(optimizer)
         hooks_off = getattr(optimizer, 'pause_hooks', None)
         # with a process group alive, RCCL's watchdog thread polls events concurrently: only this thread's calls
         # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
-        mode = 'global' if optimizer_in_graph else 'thread_local'
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            if hooks_off is not None and not optimizer_in_graph:
+        mode = 'global' if self.optimizer_in_graph else 'thread_local'
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
+            if hooks_off is not None and not self.optimizer_in_graph:
                 with hooks_off():                          # no collective may be launched while capturing
-                    self.outputs = step_fn(model, captured_opt, self.static_data, self.static_target)
+                    self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
             else:
-                self.outputs = step_fn(model, captured_opt, self.static_data, self.static_target)
+                self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
 
     def _dry_run(self, step_fn, model, optimizer):
         base = model
@@ -89,6 +116,11 @@ class GraphedTrainStep:
                 m.invalidate_key_cache()                    # the in-place restore bumped the keys' version
 
     def __call__(self, data, target):
+        if self._device_hyper:
+            self.optimizer.sync_hyper()                     # four floats, only when param_groups changed
+        elif self.optimizer_in_graph and self._hyper_signature() != self._captured_hyper:
+            self.recaptures += 1                            # e.g. MultiStepLR crossed a milestone
+            self._capture()
         self.static_data.copy_(data, non_blocking=True)
         self.static_target.copy_(target, non_blocking=True)
         self.graph.replay()

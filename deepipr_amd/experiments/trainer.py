@@ -58,6 +58,14 @@ def next_trigger_batch(state, wm_dataloader):
         return next(state['it'])
 
 
+def _check_exchange(device):
+    """Once per epoch: an in-launch partial-sum exchange of the single-pass norm kernels that ever timed out (its
+    outputs were poisoned with NaN) must stop the run, not train on."""
+    if torch.device(device).type == 'cuda':
+        from deepipr_amd import passport_ops
+        passport_ops.kernels.check_exchange()
+
+
 def train_step_v1(model, optimizer, data, target):
     """One batch: zero_grad, reset sign losses, forward, CE + sum of sign losses, backward, SGD step
     (trainer.py:128-145).  Returns device scalars (loss, sign_loss, top-1 %), no host sync."""
@@ -160,6 +168,7 @@ class Trainer(object):
         n = max(1, len(dataloader))
         sign_acc = mean_sign_acc(self.model, dev)
         s, l, a, sa = torch.cat([meters / n, sign_acc.reshape(1)]).tolist()     # the epoch's only host sync
+        _check_exchange(dev)
         if self.scheduler is not None:
             self.scheduler.step()
         return {'loss': l, 'sign_loss': s, 'sign_acc': sa, 'acc': a, 'time': time.time() - start}

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from deepipr_amd.experiments.trainer import (StepRunner, accuracy, mean_sign_acc, next_trigger_batch,
+from deepipr_amd.experiments.trainer import (StepRunner, _check_exchange, accuracy, mean_sign_acc, next_trigger_batch,
                                              reset_sign_losses, total_sign_loss)
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
@@ -137,6 +137,7 @@ class TrainerPrivate(object):
         n = max(1, len(dataloader))
         sign_acc = mean_sign_acc(self.dual, dev)
         raw = torch.cat([meters, sign_acc.reshape(1)]).tolist()                  # the epoch's only host sync
+        _check_exchange(dev)
         if self.scheduler is not None:
             self.scheduler.step()
         # the reference divides every meter by len(dataloader) except sign_loss (trainer_private.py:189-191)

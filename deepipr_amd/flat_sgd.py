@@ -31,7 +31,9 @@ _ALIGN = 64            # floats: every parameter starts on a 256-byte boundary o
 class FlatSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=1e-4, bucket_fractions=(0.45, 0.8, 0.95),
                  process_group=None):
-        params = [p for p in params]
+        # like torch.optim.SGD, frozen parameters (requires_grad=False) are never touched: they stay out of the
+        # flat buffers altogether (no weight decay, no momentum, no exchange)
+        params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -56,6 +58,12 @@ class FlatSGD(torch.optim.Optimizer):
         self.flat_buf = torch.zeros(total, dtype=torch.float32, device=dev)
         self._slots = []
         self._zero_pool = torch.zeros(_ALIGN, dtype=torch.float32, device=dev)
+        # {lr, momentum, weight_decay, 1/world} live in device memory and the update kernel reads them there: a step
+        # captured into a hipGraph (launch arguments frozen at capture) then still follows an lr schedule --
+        # sync_hyper() rewrites the four floats whenever param_groups changed (GraphedTrainStep calls it before
+        # every replay; step() calls it when it runs eagerly).
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = None
         with torch.no_grad():
             for p, off in zip(order, offsets):
                 view = self.flat_param[off:off + p.numel()].view_as(p)
@@ -153,20 +161,55 @@ class FlatSGD(torch.optim.Optimizer):
             self._launch(b, async_op=True)           # overlaps with the rest of backward
 
     # ------------------------------------------------------------------ optimiser interface
+    def sync_hyper(self):
+        """param_groups[0] -> the device-resident hyper-parameters, if they changed.  Must run OUTSIDE a hipGraph
+        capture / replay (it is a host-to-device copy of four floats on the current stream)."""
+        g = self.param_groups[0]
+        host = (float(g['lr']), float(g['momentum']), float(g['weight_decay']), 1.0 / self.world)
+        if host != self._hyper_host:
+            self._hyper.copy_(torch.tensor(host, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = host
+
+    def _missing_grads(self):
+        return [i for i, (p, _) in enumerate(self._slots) if p.grad is None]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        capturing = self.flat_param.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.sync_hyper()
+        elif self._hyper_host is None:
+            raise RuntimeError('FlatSGD: call sync_hyper() once before capturing step() into a hipGraph')
+        missing = self._missing_grads()
         for b in range(len(self._buckets)):
             if not self._launched[b]:
                 self._launch(b, async_op=False)
         for w in self._works:
             w.wait()
-        g = self.param_groups[0]
-        P.kernels.sgd_momentum_step(self.flat_param, self.flat_grad, self.flat_buf, float(g['lr']),
-                                    float(g['momentum']), float(g['weight_decay']), 1.0 / self.world)
+        if not missing:
+            P.kernels.sgd_momentum_step_dev(self.flat_param, self.flat_grad, self.flat_buf, self._hyper)
+        else:
+            # torch.optim.SGD skips parameters whose grad is None (no weight decay, no momentum update): update the
+            # runs of slots that did receive a gradient, one launch per run (rare path: unused branches)
+            skip = set(missing)
+            i, n = 0, len(self._slots)
+            while i < n:
+                if i in skip:
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < n and (j + 1) not in skip:
+                    j += 1
+                lo = self._slots[i][1]
+                last_p, last_off = self._slots[j]
+                hi = last_off + (last_p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                P.kernels.sgd_momentum_step_dev(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.flat_buf[lo:hi],
+                                                self._hyper)
+                i = j + 1
         self._works = []
         self._launched = [False] * len(self._buckets)
         self._pending = [hi - lo for lo, hi in self._buckets]

@@ -113,6 +113,7 @@ class PassportLayerBase(nn.Module):
                 y = self.passport_selection(y)
         self.register_buffer(self.KEY, x)
         self.register_buffer(self.SKEY, y)
+        self._pooled.clear()                       # new key tensors: never trust address + version alone
 
     def generate_key(self, *shape):
         shape = [1] + list(shape[1:])
@@ -192,6 +193,7 @@ class PassportLayerBase(nn.Module):
                     setattr(self, name, nn.Parameter(torch.empty(want, device=dev)))
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
+        self._pooled.clear()                       # the keys were refilled in place
 
     # ------------------------------------------------------------------ forward
     def _forward(self, x, force_passport, ind, residual=None):
@@ -224,9 +226,10 @@ class PassportLayerBase(nn.Module):
             if p_scale:
                 return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail)
             skey, key, m, stride, pad = self._pooled_means()
+            # the loss is the SignLoss module's own (its b and alpha, sign_loss.py:27: set_b() and checkpoints count)
             y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
-                x, self.weight, skey, key, self.b if sl is not None else None, m, self.bn, self.alpha, relu,
-                stride, pad, tail)
+                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad, tail)
             if sl is not None:
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
@@ -238,8 +241,8 @@ class PassportLayerBase(nn.Module):
                 return P.gn_affine_relu(x, self.scale, self.bias, self.bn, relu)
             skey, key, m, stride, pad = self._pooled_means()
             y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
-                x, self.weight, skey, key, self.b if sl is not None else None, m, self.bn, self.alpha, relu,
-                stride, pad)
+                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad)
             if sl is not None:
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
@@ -250,7 +253,8 @@ class PassportLayerBase(nn.Module):
         if not p_scale and not p_bias:               # passport branch: the fused two-launch layer
             skey, key, m, stride, pad = self._pooled_means()
             y, gamma, _beta, loss, acc, _bits = P.passport_layer(
-                x, self.weight, skey, key, self.b if sl is not None else None, m, self.alpha, relu, stride, pad)
+                x, self.weight, skey, key, sl.b if sl is not None else None, m,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad)
             if sl is not None:
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)

@@ -106,6 +106,15 @@ class HipKernels:
                                                         _stream(dev)), 'gamma_beta_bwd')
         return dw
 
+    def gamma_beta_bwd_acc(self, dgamma, dbeta, m, dw):
+        """dw += dgamma (x) m_scale + dbeta (x) m_bias, in place: `dw` already holds the data conv's wgrad."""
+        dev = _chk(dgamma, dbeta, m, dw)
+        co = dw.shape[0]
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_gamma_beta_bwd_acc(_p(dgamma), _p(dbeta), _p(m), co, dw.numel() // co,
+                                                            _p(dw), _stream(dev)), 'gamma_beta_bwd_acc')
+        return dw
+
     def gamma_beta_dkey(self, dgamma, dbeta, weight, key_shape, stride, pad):
         dev = _chk(dgamma, dbeta, weight)
         co, ci, kh, kw = weight.shape
@@ -236,12 +245,46 @@ class HipKernels:
         key = (dev.index, stream)
         buf = self._sync.get(key)
         if buf is None:
+            # The words must be created OUTSIDE a hipGraph capture: a captured zero-fill would be replayed with every
+            # step and erase the time-out flag.  Whoever captures prepares its stream first (prepare_stream).
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('deepipr_amd: the exchange words of stream %#x must exist before it is captured: '
+                                   'call passport_ops.kernels.prepare_stream(device, stream) first' % stream)
             buf = self._sync[key] = torch.zeros(_lib.SYNC_WORDS, dtype=torch.int32, device=dev)
         return buf.data_ptr()
 
+    def prepare_stream(self, dev, stream=None):
+        """Create the per-(device, stream) state the kernels need on `stream` (a torch.cuda.Stream, default: the
+        current one) ahead of a hipGraph capture on it."""
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        raw = (stream.cuda_stream if stream is not None else _stream(dev))
+        if self.allow_sync and (dev.index, raw) not in self._sync:
+            with torch.cuda.device(dev):
+                self._sync[(dev.index, raw)] = torch.zeros(_lib.SYNC_WORDS, dtype=torch.int32, device=dev)
+        self._scratch(dev, raw, 1 << 20)
+
     def sync_timeouts(self):
-        """Number of (device, stream) exchange buffers whose bounded in-kernel wait ever expired (0 = healthy)."""
+        """Number of (device, stream) exchange buffers whose bounded in-kernel wait ever expired (0 = healthy).
+        One small D2H read per buffer: call it once per epoch, not per step."""
         return sum(int(buf[_lib.SYNC_TIMEOUT_WORD].item() != 0) for buf in self._sync.values())
+
+    def check_exchange(self):
+        """Raise if an in-launch partial-sum exchange of the single-pass norm kernels ever timed out (its outputs were
+        poisoned with NaN).  The words are re-armed so that training can be restarted, e.g. with allow_sync=False."""
+        n = self.sync_timeouts()
+        if n:
+            self.reset_sync_words()
+            raise RuntimeError(
+                'deepipr_amd: %d exchange buffer(s) report an expired in-kernel wait of the single-pass norm kernels '
+                '(their workgroups were not co-resident: is another process or stream using this GPU?). The affected '
+                'outputs were poisoned with NaN. Set passport_ops.kernels.allow_sync = False to use the three-launch '
+                'form for the split-channel layers.' % n)
+
+    def reset_sync_words(self):
+        for buf in self._sync.values():
+            buf.zero_()
 
     _resident = {}
 
@@ -402,6 +445,15 @@ class HipKernels:
                                                            flat_param.numel(), lr, momentum, weight_decay,
                                                            grad_scale, _stream(dev)), 'sgd_momentum_step')
 
+    def sgd_momentum_step_dev(self, flat_param, flat_grad, flat_buf, hyper):
+        """The same with {lr, momentum, weight_decay, grad_scale} read from the 4-float DEVICE tensor `hyper`, so a
+        step captured in a hipGraph follows a learning-rate schedule."""
+        dev = _chk(flat_param, flat_grad, flat_buf, hyper)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_sgd_momentum_step_dev(_p(flat_param), _p(flat_grad), _p(flat_buf),
+                                                               flat_param.numel(), _p(hyper), _stream(dev)),
+                       'sgd_momentum_step_dev')
+
 
 kernels = HipKernels()
 
@@ -411,8 +463,12 @@ kernels = HipKernels()
 # ---------------------------------------------------------------------------------------------
 class PooledKeys:
     """Caches m = pooled_patch_mean([skey, key]) for one layer.  The cache key is the storage address
-    and in-place version counter of both tensors, so set_key / load_state_dict / an optimiser step on
-    trainable keys (passport_attack_3.py:232-243) all invalidate it."""
+    and in-place version counter of both tensors (an optimiser step on trainable keys,
+    passport_attack_3.py:232-243, bumps the version); every code path of the layer that REPLACES or refills the
+    keys (set_key, lazily drawn random keys, load_state_dict) clears the cache explicitly, because a new tensor
+    can land on a freed tensor's address with an equal version, and writes through `.data` or a c10d broadcast do
+    not bump the version at all.  Outside autograd (no_grad / inference mode, where `.data`-style writes are the
+    norm) the means are recomputed on every call."""
 
     def __init__(self):
         self._sig = None
@@ -422,9 +478,12 @@ class PooledKeys:
         if skey.shape != key.shape:
             raise RuntimeError('passport scale key %s and bias key %s must have the same shape'
                                % (tuple(skey.shape), tuple(key.shape)))
-        sig = (skey.data_ptr(), skey._version, key.data_ptr(), key._version, tuple(key.shape), key.device,
-               kh, kw, stride, pad)
-        if sig != self._sig:
+        if skey.is_inference() or key.is_inference():
+            sig = None                                    # inference tensors carry no version counter: never cache
+        else:
+            sig = (skey.data_ptr(), skey._version, key.data_ptr(), key._version, tuple(key.shape), key.device,
+                   kh, kw, stride, pad)
+        if sig is None or sig != self._sig:
             with torch.no_grad():
                 both = torch.stack([skey.detach(), key.detach()]).to(torch.float32).contiguous()
                 self._m = kernels.pooled_patch_mean(both, kh, kw, stride, pad)

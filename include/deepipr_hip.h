@@ -12,7 +12,8 @@
  *     hipGraph.  Scratch memory is passed in by the caller (`*_workspace_bytes` gives its size).
  *   - return value: DEEPIPR_OK (0) or a negative DEEPIPR_E* code; deepipr_last_error() returns a
  *     thread-local message for the last failing call on this thread.
- *   - inputs are never written; outputs are fully overwritten (no accumulate-into).
+ *   - inputs are never written; outputs are fully overwritten (the one accumulate-into entry point is
+ *     deepipr_gamma_beta_bwd_acc, named for it).
  *   - reductions are fixed-order (no float atomics): results are bit-reproducible run to run.
  */
 #ifndef DEEPIPR_HIP_H
@@ -30,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 3
+#define DEEPIPR_ABI_VERSION 4
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -93,6 +94,11 @@ int deepipr_gamma_beta_fwd(const float *W, const double *m, int Co, int K,
  *           169-173.   dW [Co][K] */
 int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double *m,
                            int Co, int K, float *dW, void *stream);
+/* The same update ADDED to dW, which already holds the data convolution's wgrad of the shared weight
+ * (passportconv2d.py:148,169,218 use one W three times): dW[co,k] += dgamma[co]*m_scale[k] + dbeta[co]*m_bias[k].
+ * 8 B per weight in one launch instead of a fresh 4 B write plus autograd's 12 B add kernel. */
+int deepipr_gamma_beta_bwd_acc(const float *dgamma, const float *dbeta, const double *m,
+                               int Co, int K, float *dW, void *stream);
 
 /* Gradient w.r.t. the passport tensors themselves (keys made nn.Parameters by
  * passport_attack_3.py:232-243).  dkeys[j][b][ci][ih][iw] = sum over patches covering (ih,iw) of
@@ -184,7 +190,9 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * not shared by calls that can run concurrently.  That form needs all its workgroups co-resident, so pass
  * sync == NULL whenever another kernel may occupy CUs of the device at the same time (e.g. a collective on a
  * second stream); channel-owning layers (C >= CUs) then still take the single pass, the others the 3-launch
- * form.  word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero if a bounded in-kernel wait ever expired.
+ * form.  If a bounded in-kernel wait ever expires, word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero AND the
+ * affected channels' statistics are poisoned with NaN (so y / dx, the loss and every gradient turn NaN): the
+ * failure cannot pass silently.  The host layer checks the word once per epoch and raises.
  * deepipr_set_resident(0) disables the single-pass kernels process-wide (testing), (1) restores the default.
  *
  * Fused residual tail (single-pass form only).  The last layer of a residual block is followed by
@@ -199,6 +207,11 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
 #define DEEPIPR_SYNC_WORDS (4096 + 16)
 #define DEEPIPR_SYNC_TIMEOUT_WORD 4096
 int deepipr_set_resident(int mode);
+/* Tuning / test knobs of the single-pass kernels, process-wide: "wg2" (two 512-thread workgroups per CU),
+ * "stagger" (s_sleep(4) rounds the second cohort of workgroups waits before loading), "split_full",
+ * "exchange_spin" (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never
+ * posts its ticket: forces the time-out path in tests; -1 = none). */
+int deepipr_debug_tune(const char *key, int value);
 int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
@@ -254,6 +267,12 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
  *           weight_decay=1e-4) from experiments/classification.py:47-50. */
 int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, size_t n, float lr,
                               float momentum, float weight_decay, float grad_scale, void *stream);
+/* The same with the four hyper-parameters read from DEVICE memory: hyper = {lr, momentum, weight_decay,
+ * grad_scale}.  Launch arguments are frozen when a step is captured into a hipGraph; with this form a replayed
+ * step follows a learning-rate schedule (MultiStepLR of experiments/classification.py:52-56, lr_configs/<name>.json):
+ * the host rewrites the floats between replays. */
+int deepipr_sgd_momentum_step_dev(float *param, const float *grad, float *momentum_buf, size_t n,
+                                  const float *hyper, void *stream);
 
 /* ------------------------------------------------------------------ residual tail of a block
  * out = relu(a + b) in one pass (12 B/element), and its backward d = dy * [out > 0] (the same gradient goes

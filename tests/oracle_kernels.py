@@ -210,3 +210,18 @@ class OracleKernels:
             d = flat_grad * grad_scale + weight_decay * flat_param
             flat_buf.mul_(momentum).add_(d)
             flat_param.add_(flat_buf, alpha=-lr)
+
+    def sgd_momentum_step_dev(self, flat_param, flat_grad, flat_buf, hyper):
+        lr, momentum, weight_decay, grad_scale = [float(v) for v in hyper.tolist()]
+        self.sgd_momentum_step(flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale)
+
+    def gamma_beta_bwd_acc(self, dgamma, dbeta, m, dw):
+        with torch.no_grad():
+            dw.add_(self.gamma_beta_bwd(dgamma, dbeta, m, dw.shape))
+        return dw
+
+    def check_exchange(self):
+        return None
+
+    def prepare_stream(self, dev, stream=None):
+        return None
