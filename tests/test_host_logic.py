@@ -13,7 +13,7 @@ import torch
 
 from oracle import runner
 from oracle.cases import CASES
-from tests.compare import compare_case
+from tests.compare import close, compare_case
 from tests.impls import ProductImpl, load_golden
 from tests.oracle_kernels import OracleKernels
 
@@ -392,3 +392,106 @@ def test_force_passport_paths(golden_dir, cpu_kernels):
     with torch.no_grad():
         _close(pv(x, force_passport=True, ind=0).cpu().numpy(), gold['force/private_forced_ind0'],
               'private forced', 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize('name', ['bk3_s2', 'bn_s1', 'sc_1x1'])
+def test_trainable_keys_match_reference_autograd(name, golden_dir, cpu_kernels):
+    """Keys as nn.Parameters (passport_attack_3.py:232-243): the product's autograd wiring of d/dkey, d/dskey and the
+    three-way dW against the REFERENCE's own autograd (goldens blocks.npz: dkey/*).  GPU twin: test_round2_gpu.py."""
+    from tests.blocks import run_dkey_case
+    gold = load_golden(golden_dir, 'blocks')
+    got = run_dkey_case(name, 'cpu')
+    for k, v in got.items():
+        close(v, gold['dkey/%s/%s' % (name, k)], k, 1e-4, 1e-5)
+
+
+def test_signloss_b_and_alpha_drive_the_fused_loss(cpu_kernels):
+    """passport_attack_3.py:261: m.sign_loss.set_b(newb) must change the training loss (models/losses/sign_loss.py:27
+    uses SignLoss.b / SignLoss.alpha), also on the fused norm paths which compute the loss inside the layer kernel."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    torch.manual_seed(4)
+    np.random.seed(4)
+    x = torch.randn(4, 4, 8, 8)
+    for norm in ('bn', 'gn', 'none'):
+        blk = PassportBlock(4, 32, 3, 1, 1, {'norm_type': norm, 'key_type': 'random', 'sign_loss': 0.5})
+        blk(x)
+        gamma = blk.sign_loss.scale_cache.detach().view(-1)
+        before = float(blk.sign_loss.loss)
+        newb = -torch.sign(gamma)                              # every bit wrong: the hinge is active everywhere
+        blk.sign_loss.set_b(newb)
+        blk.sign_loss.alpha = 0.25
+        blk(x)
+        want = float((0.25 * torch.relu(-newb * gamma + 0.1)).sum() + 1e-5 * gamma.pow(2).sum())
+        assert float(blk.sign_loss.loss) == pytest.approx(want, rel=1e-5), norm
+        assert float(blk.sign_loss.loss) != pytest.approx(before, rel=1e-3)
+        assert float(blk.sign_loss.acc) == 0.0
+
+
+def test_pooled_key_cache_is_dropped_when_keys_are_replaced(cpu_kernels):
+    """set_key twice with no forward in between, a `.data` write and a load_state_dict must all be seen by the next
+    forward (the cache of pooled passport means is keyed on address + version only as a fast path)."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    torch.manual_seed(5)
+    kw = {'norm_type': 'bn', 'key_type': 'shuffle', 'sign_loss': 0.1}
+    blk = PassportBlock(4, 16, 3, 1, 1, kw).eval()
+    k1, k2 = torch.rand(1, 4, 8, 8) * 2 - 1, torch.rand(1, 4, 8, 8) * 2 - 1
+
+    def gamma_direct(skey):
+        return torch.nn.functional.conv2d(skey, blk.weight, None, 1, 1).mean(dim=(0, 2, 3)).detach()
+    with torch.no_grad():
+        blk.set_key(k1.clone(), k1.clone())
+        assert torch.allclose(blk.get_scale().view(-1), gamma_direct(k1), rtol=1e-5, atol=1e-6)
+        blk.set_key(k2.clone(), k2.clone())
+        assert torch.allclose(blk.get_scale().view(-1), gamma_direct(k2), rtol=1e-5, atol=1e-6)
+        blk.skey.data.copy_(k1)                                 # no version bump on `skey`
+        blk.invalidate_key_cache()
+        assert torch.allclose(blk.get_scale().view(-1), gamma_direct(k1), rtol=1e-5, atol=1e-6)
+        sd = blk.state_dict()
+        sd['skey'] = k2.clone()
+        blk.load_state_dict(sd)
+        assert torch.allclose(blk.get_scale().view(-1), gamma_direct(k2), rtol=1e-5, atol=1e-6)
+
+
+def test_flat_sgd_skips_frozen_and_gradless_parameters_like_torch_sgd(cpu_kernels):
+    """torch.optim.SGD (experiments/classification.py:47-50) leaves parameters with requires_grad=False or grad None
+    untouched -- no weight decay, no momentum.  FlatSGD must do the same."""
+    from deepipr_amd.flat_sgd import FlatSGD
+    torch.manual_seed(6)
+
+    def make():
+        torch.manual_seed(6)
+        net = torch.nn.ModuleList([torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)])
+        net[1].weight.requires_grad_(False)                    # frozen
+        return net
+    a, b = make(), make()
+    oa = torch.optim.SGD([p for p in a.parameters() if p.requires_grad], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    ob = FlatSGD(b.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    x = torch.randn(5, 8)
+    for step in range(3):
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad(set_to_none=True)
+            h = net[1](net[0](x))
+            if step != 1:                                      # step 1: the last layer is unused -> its grads are None
+                h = net[2](h)
+            h.square().sum().backward()
+            opt.step()
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), na
+    assert torch.equal(a[1].weight, make()[1].weight)          # the frozen one never moved
+
+
+def test_flat_sgd_device_hypers_follow_the_scheduler(cpu_kernels):
+    """The update reads lr from FlatSGD's 4-float tensor; sync_hyper() tracks param_groups (MultiStepLR)."""
+    from deepipr_amd.flat_sgd import FlatSGD
+    lin = torch.nn.Linear(4, 4)
+    opt = FlatSGD(lin.parameters(), lr=0.5, momentum=0.0, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [1], 0.1)
+    w0 = lin.weight.detach().clone()
+    lin.weight.grad = torch.ones_like(lin.weight)
+    lin.bias.grad = torch.zeros_like(lin.bias)
+    opt.step()
+    assert torch.allclose(lin.weight, w0 - 0.5)
+    sched.step()
+    opt.step()
+    assert torch.allclose(lin.weight, w0 - 0.5 - 0.05)
+    assert opt._hyper.tolist() == pytest.approx([0.05, 0.0, 0.0, 1.0])

@@ -1071,7 +1071,9 @@ def test_product_has_no_cpu_path():
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
     blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
     with pytest.raises(RuntimeError, match='GPU only'):
-        blk(torch.randn(2, 4, 8, 8))@pytest.mark.gpu
+        blk(torch.randn(2, 4, 8, 8))
+
+
 def test_weight_shuttle_with_key_derived_gamma_beta(golden_dir):
     """load_passport_model_to_normal_model (experiments/utils.py:191-239) on a V1 net without learnable scale/bias:
     the plain net's norm weights become gamma/beta computed from the keys by the HIP GEMV."""
@@ -1090,7 +1092,6 @@ def test_weight_shuttle_with_key_derived_gamma_beta(golden_dir):
             assert np.array_equal(got[k], want[k]), k
 
 
-@pytest.mark.gpu
 def test_force_passport_paths_on_gpu(golden_dir):
     """flip_attack.py:25 / pruning_attack.py:26 / passportconv2d.py:142-175: with the learnable pair installed
     (init_scale/init_bias(True), what the weight shuttles do) plain calls use it, force_passport=True returns to the
