@@ -13,8 +13,8 @@ zero_grad -> forward -> CE + sum of sign losses -> backward -> SGD(0.01, 0.9, wd
 Rank 0 prints ONE JSON line with the whole-job images/sec, plus
   roofline      the dominant hand-written kernel (single-pass norm + passport affine + ReLU backward), timed in
                 situ with start/stop HIP events on each dispatch of it, on its launch stream: during the timed
-                region when that runs eagerly (several GPUs, --eager), on eager steps of the same job right after it
-                when the timed region is replayed from a hipGraph (the one-GPU default; config.launch says which)
+                region when that runs eagerly (--eager, --ddp), on eager steps of the same job right after it
+                when the timed region is replayed from a hipGraph (the default; config.launch says which)
   cpu_baseline  the oracle's CPU step ("port") on this host's cores, bounded sample, N=1 only
 """
 import argparse
@@ -214,8 +214,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
-    ap.add_argument('--graph', action='store_true', help='hipGraph replay of the step (the default on one GPU)')
-    ap.add_argument('--eager', action='store_true', help='eager dispatch of the timed region also on one GPU')
+    ap.add_argument('--graph', action='store_true', help='hipGraph replay of the step (the default; kept for compatibility)')
+    ap.add_argument('--eager', action='store_true', help='eager dispatch of the timed region (exchange overlapped with backward)')
     ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
     ap.add_argument('--ddp-static-graph', type=int, default=1, help='DistributedDataParallel(static_graph=...)')
     args = ap.parse_args()
@@ -263,13 +263,18 @@ def main():
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
 
     all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
-    # Launch mode of the timed region.  One GPU: the whole step (zero_grad .. optimiser) is replayed from a hipGraph
-    # by default -- the step issues ~280 dispatches, and on a box with a slow or busy host the eager enqueue
-    # (4.5-6.5 ms) rather than the GPU (5.6 ms) sets the pace; replay takes the host out of the measurement.
-    # Several GPUs: eager, so that FlatSGD's bucketed all-reduces overlap with backward (--graph replays forward +
-    # backward and runs the exchange eagerly after it).  --eager forces eager everywhere.
+    # Launch mode of the timed region: hipGraph replay by default.  The step issues ~260 dispatches (~500 for the
+    # dual-forward V2/V3 step); eager enqueue costs 4.5-9 ms of host time against 5.1-5.6 ms of GPU time, so an eager
+    # step is host-bound exactly where it matters most (32 images per GPU in config P).
+    #   one GPU      : the whole step (zero_grad .. optimiser) is one graph;
+    #   several GPUs : zero_grad .. backward is one graph; FlatSGD's bucketed RCCL all-reduces and the fused SGD
+    #                  kernel are enqueued eagerly after each replay (no collective is ever captured).  The exchange
+    #                  (44.7 MB, ~0.5 ms over xGMI at N = 8) is then not hidden behind backward, but the step no
+    #                  longer waits for the host -- measured on one GPU with the exchange forced on
+    #                  (DEEPIPR_FORCE_DDP=1): see DESIGN.md 5.
+    # --eager: eager dispatch with the exchange overlapped with backward; --ddp: DistributedDataParallel (eager).
     eager_step = step
-    use_graph = (args.graph or (args.gpus == 1 and not args.eager)) and not args.ddp
+    use_graph = not args.eager and not args.ddp
     if use_graph:
         try:
             from deepipr_amd.experiments.graph_step import GraphedTrainStep
@@ -282,6 +287,8 @@ def main():
                   file=sys.stderr)
             torch.cuda.synchronize()
             use_graph, step = False, eager_step
+    import torch.distributed as _td
+    tdist_on = _td.is_available() and _td.is_initialized()
     for i in range(args.warmup):
         step(i)
     timing = not args.no_kernel_timing
@@ -353,8 +360,9 @@ def main():
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
-                   'launch': ('hipGraph replay of the whole step; kernel timing from %d eager steps right after the timed '
-                              'region' % sampled) if use_graph else 'eager'},
+                   'launch': (('hipGraph replay of %s; kernel timing from %d eager steps right after the timed region'
+                               % ('the whole step' if not tdist_on else 'zero_grad..backward, then eager bucketed '
+                                  'all-reduce + fused SGD', sampled)) if use_graph else 'eager')},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
                  'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',
@@ -365,7 +373,10 @@ def main():
                  'bn_bwd_reduce': 'backward channel sums (8 B/elt)', 'bn_stats': 'batch statistics (4 B/elt)',
                  'affine_bwd': 'affine backward: read dy + xhat, write dxhat (12 B/elt)',
                  'affine_fwd': 'affine forward (8 B/elt)', 'sgd': 'fused SGD over the flat buffers (20 B/param)'}
-    if timing and any(prof.get(k, (0, 0))[1] > 0 for k in STREAMING):
+    if out['exchange_timeouts']:
+        out['roofline_refused'] = ('an in-launch exchange of the single-pass kernels timed out (%d buffer(s)): their '
+                                   'outputs were poisoned; no roofline is reported for this run' % out['exchange_timeouts'])
+    if timing and not out['exchange_timeouts'] and any(prof.get(k, (0, 0))[1] > 0 for k in STREAMING):
         # Durations come from start/stop events attached to each kernel's own dispatch (hipExtLaunchKernelGGL):
         # kernel execution time, comparable with rocprofv3's kernel trace.  The library also accounts the
         # algorithmic bytes of every timed launch (deepipr_profile_read_bytes), so achieved = bytes / kernel time

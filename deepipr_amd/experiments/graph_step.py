@@ -71,24 +71,37 @@ class GraphedTrainStep:
     def _capture(self):
         from deepipr_amd import passport_ops
         optimizer = self.optimizer
+        kernels = passport_ops.kernels
         optimizer.zero_grad(set_to_none=True)
-        passport_ops.kernels.prepare_stream(self.static_data.device, self.stream)
-        self._device_hyper = hasattr(optimizer, 'sync_hyper')
-        if self._device_hyper:
-            optimizer.sync_hyper()
-        self._captured_hyper = self._hyper_signature()
-        self.graph = torch.cuda.CUDAGraph()
-        captured_opt = optimizer if self.optimizer_in_graph else _NoStep(optimizer)
         hooks_off = getattr(optimizer, 'pause_hooks', None)
-        # with a process group alive, RCCL's watchdog thread polls events concurrently: only this thread's calls
-        # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
-        mode = 'global' if self.optimizer_in_graph else 'thread_local'
-        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
-            if hooks_off is not None and not self.optimizer_in_graph:
-                with hooks_off():                          # no collective may be launched while capturing
+        # Data-parallel replay with FlatSGD: every collective of a step is enqueued by optimizer.step() AFTER the
+        # replay and is waited for before the SGD kernel, i.e. before the next replay starts -- no RCCL kernel ever
+        # shares the device with the captured kernels, so the split-channel single-pass kernels (which need all
+        # their workgroups co-resident) can stay on inside the graph although FlatSGD switched them off for the
+        # eager, overlapped exchange.
+        exchange_after_replay = (not self.optimizer_in_graph) and hooks_off is not None
+        saved_allow = kernels.allow_sync
+        if exchange_after_replay:
+            kernels.allow_sync = True
+        try:
+            kernels.prepare_stream(self.static_data.device, self.stream)
+            self._device_hyper = hasattr(optimizer, 'sync_hyper')
+            if self._device_hyper:
+                optimizer.sync_hyper()
+            self._captured_hyper = self._hyper_signature()
+            self.graph = torch.cuda.CUDAGraph()
+            captured_opt = optimizer if self.optimizer_in_graph else _NoStep(optimizer)
+            # with a process group alive, RCCL's watchdog thread polls events concurrently: only this thread's calls
+            # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
+            mode = 'global' if self.optimizer_in_graph else 'thread_local'
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
+                if exchange_after_replay:
+                    with hooks_off():                      # no collective may be launched while capturing
+                        self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
+                else:
                     self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
-            else:
-                self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
+        finally:
+            kernels.allow_sync = saved_allow
 
     def _dry_run(self, step_fn, model, optimizer):
         base = model
