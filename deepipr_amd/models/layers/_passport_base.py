@@ -68,6 +68,7 @@ class PassportLayerBase(nn.Module):
         self.relu = nn.ReLU(inplace=True) if relu else None
         self._pooled = P.PooledKeys()
         self.fuse_norm = True          # fold BatchNorm(affine=False) into the passport kernels when possible
+        self.fuse_conv = True          # ... and run the data conv inside that node (in-place three-way dW)
         self.reset_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -212,13 +213,34 @@ class PassportLayerBase(nn.Module):
             self.set_key(torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device),
                          torch.tensor(self.generate_key(*x.size()), dtype=x.dtype, device=x.device))
 
+    def _conv_inside(self, x):
+        """The data convolution can run inside the fused node (passport_ops._PassportBNLayer, `conv`): a plain
+        bias-free conv nobody hooked, fp32 input (host tensors are refused by the kernels further down)."""
+        c = self.conv
+        return (self.fuse_conv and x.dtype == torch.float32 and x.dim() == 4 and c.bias is None
+                and c.groups == 1 and tuple(c.dilation) == (1, 1) and c.padding_mode == 'zeros'
+                and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks)
+
     def _layer(self, x, force_passport, ind, residual):
         self.ensure_key(x)
-        x = self.conv(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
         p_bias = self._use_param(self.bias, force_passport, ind)
         sl = self._sign()
+        if (self.fuse_norm and P.bn_is_fusable(self.bn) and not p_scale and not p_bias and self._conv_inside(x)):
+            # passport branch with the data convolution inside the fused node: the shared weight's three-way
+            # gradient is formed in MIOpen's wgrad buffer (deepipr_gamma_beta_bwd_acc), no extra dW + add pass
+            oshape = P.conv_out_shape(x, self.conv)
+            tail = residual if (residual is not None and P.bn_tail_fusable(self.bn, oshape)) else None
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
+                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad, tail, conv_inside=True)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
+        x = self.conv(x)
         if self.fuse_norm and P.bn_is_fusable(self.bn) and p_scale == p_bias:
             # BatchNorm(affine=False) folded into the passport kernels: 3 launches forward, 3 backward,
             # the normalised activation is never written (deepipr_passport_bn_fwd / _bwd)

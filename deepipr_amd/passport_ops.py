@@ -617,13 +617,23 @@ class _PassportBNLayer(torch.autograd.Function):
     is never written.  With weight=None it is the public branch of a PassportPrivateBlock (learnable gamma_in /
     beta_in).  With `residual` the block's tail relu(layer + residual) is folded in as well.  The output comes
     out twice (y, y'): two handles of the same tensor for the two consumers of a residual block's output, whose
-    gradients are then summed inside the backward kernel (tail form) instead of by an ATen add."""
+    gradients are then summed inside the backward kernel (tail form) instead of by an ATen add.
+
+    `conv` = (stride, pad): `x` is the layer's INPUT and the data convolution with the same `weight` runs inside
+    this node (aten::convolution -> MIOpen, unchanged).  The point is the shared weight's three-way gradient
+    (models/layers/passportconv2d.py:148,169,218 use one W three times): backward calls MIOpen's wgrad and then ADDS
+    the passport branch's rank-2 update into that buffer (deepipr_gamma_beta_bwd_acc, 8 B per weight) instead of
+    writing a second full-size dW that autograd sums with an extra 12 B-per-weight add kernel."""
 
     @staticmethod
     def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, residual, cfg):
-        alpha, relu, stride, pad, training, momentum, eps = cfg
+        alpha, relu, stride, pad, training, momentum, eps, conv = cfg
         x = x.contiguous()
         w = None if weight is None else weight.contiguous()
+        x_in = None
+        if conv is not None:
+            x_in = x
+            x = torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
@@ -632,7 +642,7 @@ class _PassportBNLayer(torch.autograd.Function):
             x, w, m, gi, bi, bb, float(alpha), relu, running_mean, running_var, nbt, float(momentum), float(eps),
             training, residual=res)
         ctx.tail = res is not None
-        ctx.save_for_backward(x, w, table, m, bb, y if ctx.tail else None)
+        ctx.save_for_backward(x, w, table, m, bb, y if ctx.tail else None, x_in)
         ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
         ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as freshly filled zeros
         # running_mean / running_var / num_batches_tracked are plain buffers updated in place by the kernel
@@ -646,7 +656,7 @@ class _PassportBNLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy2, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
-        x, w, table, m, bb, tail_out = ctx.saved_tensors
+        x, w, table, m, bb, tail_out, x_in = ctx.saved_tensors
         alpha, relu, stride, pad, training, key_shape = ctx.cfg
         if dy is None:
             dy, dy2 = dy2, None
@@ -657,12 +667,21 @@ class _PassportBNLayer(torch.autograd.Function):
         dl = None if (bb is None or dloss is None) else dloss.contiguous()
         if w is None:
             dgamma_extra = dbeta_extra = None
+        in_node_conv = x_in is not None
+        # with the convolution inside this node the fresh dW is NOT written: the rank-2 update goes into MIOpen's
+        # wgrad below (wshape None = "no dW" for the kernel; dgamma / dbeta still carry the sign-loss gradient)
         out = kernels.passport_bn_bwd(dy.contiguous(), x, table, m, bb, alpha, dl,
                                       _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
-                                      None if w is None else w.shape, relu, training,
+                                      None if (w is None or in_node_conv) else w.shape, relu, training,
                                       dy2=None if dy2 is None else dy2.contiguous(), tail_out=tail_out)
         dx, dw, dg, db = out[:4]
         dres = out[4] if ctx.tail else None
+        if in_node_conv:
+            need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+            dx, dw, _ = torch.ops.aten.convolution_backward(
+                dx, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
+            if need_dw:
+                dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw.contiguous())
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
@@ -670,17 +689,19 @@ class _PassportBNLayer(torch.autograd.Function):
                 dg if w is None else None, db if w is None else None, None, None, None, None, None, dres, None)
 
 
-def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual):
-    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps)
+def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual, conv=None):
+    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps, conv)
     return _PassportBNLayer.apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked if bn.training else None, residual, cfg)
 
 
-def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None):
+def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None, conv_inside=False):
     """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False).
+    conv_inside: `x` is the layer's INPUT; the data convolution runs inside the node and the shared weight's
+    gradient is accumulated in place (see _PassportBNLayer).
     -> y, gamma, beta, loss, acc, bits; with `residual` y is the PAIR of handles of relu(layer + residual)."""
     y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, None, None, b, m, bn, alpha, relu, stride,
-                                                    pad, residual)
+                                                    pad, residual, (stride, pad) if conv_inside else None)
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
@@ -691,15 +712,24 @@ def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None):
     return (out[0], out[1]) if residual is not None else out[0]
 
 
+def conv_out_shape(x, conv):
+    """Shape of conv(x) for a plain square-geometry nn.Conv2d (no dilation / groups)."""
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    return (x.shape[0], conv.out_channels, (x.shape[2] + 2 * p - k) // s + 1, (x.shape[3] + 2 * p - conv.kernel_size[1]) // s + 1)
+
+
 def bn_tail_fusable(bn, x):
     """The residual tail can be folded into this layer's kernels: a BatchNorm2d on batch statistics and a shape
-    that takes the single-pass form in both directions."""
+    that takes the single-pass form in both directions.  `x`: the conv output, or its shape."""
     # DEEPIPR_TAIL_FUSION=0 keeps the separate tail kernels (deepipr_add_relu_fwd / deepipr_relu_bwd2); both forms are
     # bit-identical (tests/test_parity_gpu.py::test_tail_fusion_is_bit_identical_at_model_level).
     if os.environ.get('DEEPIPR_TAIL_FUSION', '1') == '0':
         return False
     if not isinstance(bn, torch.nn.BatchNorm2d) or bn.momentum is None or not _bn_uses_batch_stats(bn):
         return False
+    if not isinstance(x, torch.Tensor):
+        n, c, h, w = x
+        return kernels.bn_resident(n, c, h * w) == 3
     if x.dim() != 4 or x.dtype != torch.float32:
         return False
     n, c = x.shape[0], x.shape[1]
