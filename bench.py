@@ -189,12 +189,17 @@ def stress_roofline(device, reps=30):
             'bytes_per_launch': a['bytes_per_launch'], 'avg_us': a['avg_us'], 'kernels': res}
 
 
-def pmc_traffic(kernel, shape_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic.json), or None."""
+def pmc_traffic(kernel, shape_key, algorithmic=None):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None.
+    PMC counters need their own rocprofv3 runs (separate FETCH_SIZE / WRITE_SIZE passes), so they cannot be taken
+    inside this process; the committed record is quoted only when it was measured on the SAME launch mix, i.e. when
+    the algorithmic bytes per launch recorded with it equal the ones accounted in this run (`algorithmic`)."""
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))[kernel][shape_key]
+        if algorithmic is not None and abs(rec['algorithmic'] / algorithmic - 1.0) > 0.01:
+            return None
         return int(rec['fetch'] + rec['write'])
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
@@ -400,13 +405,12 @@ def main():
         dom = max((k for k in kern if k in STREAMING and k != 'sgd'), key=lambda k: kern[k]['us_per_step'])
         a = kern[dom]
         per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
-        # PMC traffic (profiles/pmc_traffic.json) was collected per shape for the plain single pass; with the residual
-        # tails folded into 8 of the 20 launches the step's mix moves more bytes per launch, so it is quoted only when
-        # it describes the same launch mix (the per-shape PMC / algorithmic ratios are in DESIGN.md 4)
-        pmc_bytes = pmc_traffic('k_' + dom, 'in_situ_per_launch')
+        # PMC traffic: rocprofv3 --pmc passes over this very command (tools/gpu_pmc_in_situ.sh, summarised into
+        # profiles/pmc_traffic.json: in_situ_per_launch), quoted when that record describes this launch mix
+        pmc_bytes = pmc_traffic('k_' + dom, 'in_situ_per_launch', per_launch)
         out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
-                           'traffic': pmc_bytes if pmc_bytes and abs(pmc_bytes / per_launch - 1.0) < 0.05 else None,
+                           'traffic': pmc_bytes,
                            'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
                            'launches_per_step': a['launches_per_step'],
                            'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '

@@ -50,6 +50,7 @@ SIGNATURES = {
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
+    'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
                                        _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,

@@ -162,11 +162,15 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ReLU as ATen computes it (clamp_min: NaN propagates).  fmaxf(NaN, 0) would return 0 and silently swallow a
+// poisoned statistic (res_exchange time-out) or an upstream NaN.
+__device__ __forceinline__ float relu1(float y) { return y < 0.0f ? 0.0f : y; }
+
 // y = relu?(g*x + b) with the reference's two roundings (aten::mul then aten::add).
 template <bool RELU>
 __device__ __forceinline__ float affine1(float x, float g, float b) {
     float y = __fadd_rn(__fmul_rn(g, x), b);
-    return RELU ? fmaxf(y, 0.0f) : y;
+    return RELU ? relu1(y) : y;
 }
 
 // ============================================================================================
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_walk_large(
 template <bool RELU>
 __device__ __forceinline__ float bn_affine1(float x, const float4 &c) {       // c = {mean, invstd, gamma, beta}
     const float y = __fadd_rn(__fmul_rn(c.z, (x - c.x) * c.y), c.w);
-    return RELU ? fmaxf(y, 0.0f) : y;
+    return RELU ? relu1(y) : y;
 }
 
 template <bool RELU>
@@ -1331,7 +1335,15 @@ struct ResPlan {
     int drop;             // test hook: this slice never posts its ticket (-1 = none)
     int stagger;          // s_sleep(4) rounds the second cohort of workgroups waits before loading (2 per CU)
     int cohort;           // workgroups below this index are the first cohort
+    unsigned long long *trace;   // debug: [block][8] wall-clock stamps (100 MHz) of the kernel's phases, or nullptr
 };
+
+// Phase stamps of one workgroup (thread 0): 0 entry, 1 loads consumed + block sums done, 2 exchange done,
+// 3 channel table ready, 4 all stores issued.  deepipr_debug_trace() arms it; nullptr in production.
+__device__ __forceinline__ void res_stamp(const ResPlan &pl, int slot) {
+    if (pl.trace && threadIdx.x == 0)
+        pl.trace[static_cast<size_t>(blockIdx.x) * 8 + slot] = wall_clock64();
+}
 
 __device__ __forceinline__ void sc1_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
@@ -1475,6 +1487,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
     // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
+    res_stamp(pl, 0);
     res_stagger(pl);
     const float K = reinterpret_cast<const float *>(x)[static_cast<size_t>(c0 + c_local) * pl.q4 * 4];
     float4 v[F4];
@@ -1502,6 +1515,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
     }
     double s1 = static_cast<double>(a0), s2 = static_cast<double>(a1);
     res_block_sums<T>(s1, s2, pl, c_local, red);
+    res_stamp(pl, 1);
     if (pl.S > 1) {                                   // G == 1 here
         if (t == 0) {
             res_exchange(s1, s2, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
@@ -1512,6 +1526,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
         s1 = xch[0];
         s2 = xch[1];
     }
+    res_stamp(pl, 2);
     if (t < pl.gq && t == c_local * pl.q4) {          // one thread per local channel
         const int c = c0 + c_local;
         const double dmu = s1 * f.inv_m;                               // mean - K
@@ -1534,6 +1549,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
     }
     if (blockIdx.x == 0 && t == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
     __syncthreads();
+    res_stamp(pl, 3);
     const float4 ch = chan[c_local];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
@@ -1549,12 +1565,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
             }
             if (residual) {                          // the block's tail: relu(layer output + shortcut)
                 const float4 r = residual[idx[k]];
-                o = make_float4(fmaxf(o.x + r.x, 0.0f), fmaxf(o.y + r.y, 0.0f), fmaxf(o.z + r.z, 0.0f),
-                                fmaxf(o.w + r.w, 0.0f));
+                o = make_float4(relu1(o.x + r.x), relu1(o.y + r.y), relu1(o.z + r.z), relu1(o.w + r.w));
             }
             y[idx[k]] = o;
         }
     }
+    res_stamp(pl, 4);
 }
 
 struct ResBwdArgs {
@@ -1588,6 +1604,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    res_stamp(pl, 0);
     res_stagger(pl);
     const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
     float4 dz[F4], xh[F4];
@@ -1633,6 +1650,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
     }
     double ag = static_cast<double>(a0), ab = static_cast<double>(a1);
     res_block_sums<T>(ag, ab, pl, c_local, red);
+    res_stamp(pl, 1);
     if (pl.S > 1) {
         if (t == 0) {
             res_exchange(ag, ab, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
@@ -1643,6 +1661,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
         ag = xch[0];
         ab = xch[1];
     }
+    res_stamp(pl, 2);
     if (s == 0 && t < pl.gq && t == c_local * pl.q4) {
         const int c = c0 + c_local;
         float dg = static_cast<float>(ag), db = static_cast<float>(ab);
@@ -1662,6 +1681,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
                                      sc * (dz[k].z - c2 - xh[k].z * c3), sc * (dz[k].w - c2 - xh[k].w * c3));
         }
     }
+    res_stamp(pl, 4);
 }
 
 // ============================================================================================
@@ -1931,11 +1951,10 @@ __global__ __launch_bounds__(kThreads) void k_add_relu_fwd(const float *__restri
     float4 *o4 = reinterpret_cast<float4 *>(out);
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += step) {
         const float4 u = a4[i], v = b4[i];
-        o4[i] = make_float4(fmaxf(u.x + v.x, 0.0f), fmaxf(u.y + v.y, 0.0f), fmaxf(u.z + v.z, 0.0f),
-                            fmaxf(u.w + v.w, 0.0f));
+        o4[i] = make_float4(relu1(u.x + v.x), relu1(u.y + v.y), relu1(u.z + v.z), relu1(u.w + v.w));
     }
     for (size_t i = n4 * 4 + static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += step)
-        out[i] = fmaxf(a[i] + b[i], 0.0f);
+        out[i] = relu1(a[i] + b[i]);
 }
 
 // TWO: the gradient arrives in two pieces (the two consumers of a block's output: the next block's first conv and
@@ -2375,6 +2394,7 @@ struct ResTune {
     std::atomic<int> split_full{0};   // 1: split channels over slices whenever they do not fill the chip (not just < half)
     std::atomic<int> spin{static_cast<int>(kSpinLimit)};
     std::atomic<int> drop{-1};        // test hook: slice that never posts its exchange ticket
+    std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace)
 };
 ResTune g_tune;
 
@@ -2432,6 +2452,7 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     pl.drop = g_tune.drop.load(std::memory_order_relaxed);
     pl.stagger = (per_cu == 2 && pl.blocks > cus) ? g_tune.stagger.load(std::memory_order_relaxed) : 0;
     pl.cohort = cus;
+    pl.trace = g_tune.trace.load(std::memory_order_relaxed);
     *out = pl;
     return true;
 }
@@ -2556,6 +2577,11 @@ int deepipr_debug_tune(const char *key, int value) {
     else if (k == "exchange_spin") g_tune.spin.store(value <= 0 ? static_cast<int>(kSpinLimit) : value);
     else if (k == "exchange_drop") g_tune.drop.store(value);
     else return fail(DEEPIPR_EINVAL, "debug_tune: unknown key '%s'", key);
+    return DEEPIPR_OK;
+}
+
+int deepipr_debug_trace(unsigned long long *device_buffer) {
+    g_tune.trace.store(device_buffer);
     return DEEPIPR_OK;
 }
 

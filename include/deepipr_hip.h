@@ -212,6 +212,11 @@ int deepipr_set_resident(int mode);
  * "exchange_spin" (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never
  * posts its ticket: forces the time-out path in tests; -1 = none). */
 int deepipr_debug_tune(const char *key, int value);
+/* Phase tracing of the single-pass kernels (measurement only): while device_buffer != NULL, thread 0 of every
+ * workgroup of k_bn_res_fwd / _bwd writes five 100 MHz wall-clock stamps to device_buffer[block][8]: entry, loads
+ * consumed + workgroup sums formed, exchange done, channel table ready, all stores issued.  The buffer needs
+ * 8 * 8 bytes per workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */
+int deepipr_debug_trace(unsigned long long *device_buffer);
 int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
