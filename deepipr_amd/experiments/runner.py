@@ -170,7 +170,11 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
         opt = FlatSGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001)
         wrap = lambda m: m
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
-    graph = bool(args.get('graph')) and not args.get('ddp')      # DDP's own hooks cannot be captured
+    # hipGraph replay: opt-in on one GPU (--graph), the default with several (--eager switches it off): at 32-64
+    # images per GPU the eager step is host-bound (~500 dispatches), a replayed one is not.  DDP's own hooks cannot
+    # be captured.
+    graph = (bool(args.get('graph')) or (world > 1 and device.type == 'cuda' and not args.get('eager'))) \
+        and not args.get('ddp')
     if private:
         net = wrap(DualBranch(model))
         trainer = TrainerPrivate(net, opt, sched, device, graph=graph)

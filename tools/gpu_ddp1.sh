@@ -1,12 +1,26 @@
 #!/bin/bash
 # Single-GPU rehearsal of the multi-GPU launch path (the driver owns the real 8-GPU runs): torch.distributed.run,
 # nccl (= RCCL) init, rank-0 state broadcast, FlatSGD's bucketed exchange forced on in a world of one
-# (DEEPIPR_FORCE_DDP=1), the hipGraph (forward+backward) + eager exchange form, and the DDP alternative.
-export DEEPIPR_FORCE_DDP=1
+# (DEEPIPR_FORCE_DDP=1).  For config R (V1, 128 images/GPU) and the config-P shard (V2, 32 images/GPU):
+#   default  = what N > 1 ranks run: hipGraph replay of zero_grad..backward + eager bucketed exchange + fused SGD
+#   --eager  = eager dispatch with the exchange overlapped with backward
+#   single   = the plain one-GPU run (whole step in one graph, no exchange): the number the scaling is judged against
+# Full JSON lines -> gpurun_out/${R}_ddp_rehearsal.jsonl
+mkdir -p gpurun_out
+R=${ROUND_TAG:-r02}
+OUT=gpurun_out/${R}_ddp_rehearsal.jsonl
+: > $OUT
 RUN="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511"
-# (with --gpus 1 bench.py would default to graph replay: --eager = what N > 1 ranks run)
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --eager 2>&1 | grep '"metric"' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --graph 2>&1 | grep -E '"metric"|Error' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --scheme 2 --classes 100 --batch 32 --eager 2>&1 | grep '"metric"' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --scheme 2 --classes 100 --batch 32 --graph 2>&1 | grep -E '"metric"|Error' | cut -c1-200
-$RUN bench.py --gpus 1 --steps 40 --warmup 10 --no-cpu-baseline --no-stress --ddp --eager 2>&1 | grep '"metric"' | cut -c1-200
+COMMON="--gpus 1 --steps 60 --warmup 15 --no-cpu-baseline --no-stress --no-kernel-timing"
+for cfg in "" "--scheme 2 --classes 100 --batch 32"; do
+  for mode in "" "--eager"; do
+    DEEPIPR_FORCE_DDP=1 $RUN bench.py $COMMON $cfg $mode 2>&1 | grep -E '"metric"' | sed "s/^{/{\"rehearsal\": \"exchange forced on, ${mode:-default (graph + eager exchange)}\", /" >> $OUT
+  done
+  python bench.py $COMMON $cfg 2>&1 | grep -E '"metric"' | sed 's/^{/{"rehearsal": "single GPU, whole step in one graph, no exchange", /' >> $OUT
+done
+python - "$OUT" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l)
+    print('%-60s %-50s %8.1f img/s %7.3f ms' % (d['rehearsal'], d['config']['workload'][:50], d['value'], d['ms_per_step']))
+PY
