@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdeepipr_hip.so')
+# DEEPIPR_LIB: measurement builds only (csrc/libdeepipr_hip_trace.so, `make -C deepipr_amd/csrc trace`)
+LIB_PATH = os.environ.get('DEEPIPR_LIB') or os.path.join(_HERE, 'csrc', 'libdeepipr_hip.so')
 
 _c = ctypes
 _f32p, _f64p, _i8p, _vp = _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p   # raw device addresses
@@ -70,8 +71,8 @@ SIGNATURES = {
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
 ABI_VERSION = 4
-SYNC_WORDS = 4096 + 16           # DEEPIPR_SYNC_WORDS
-SYNC_TIMEOUT_WORD = 4096        # DEEPIPR_SYNC_TIMEOUT_WORD
+SYNC_WORDS = 2 * 256 * 30 * 4 + 16     # DEEPIPR_SYNC_WORDS
+SYNC_TIMEOUT_WORD = 2 * 256 * 30 * 4   # DEEPIPR_SYNC_TIMEOUT_WORD
 
 
 class HipLibraryMissing(RuntimeError):

@@ -1321,9 +1321,13 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 //     reports through sync[kSyncTimeoutWord].
 // Fixed-order sums throughout: bit-reproducible run to run.
 // ============================================================================================
-constexpr int kSyncCounters = 4096;
-constexpr int kSyncTimeoutWord = kSyncCounters;
-constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(4): a few seconds
+// Exchange buffer (`sync`, DEEPIPR_SYNC_WORDS 32-bit words = granules of 8 bytes): for every slice count S in
+// {2, 4, 8, 16} a region of kXchChannels x S slots of 4 granules; then the time-out word.
+constexpr int kXchChannels = 256;                  // channels are split only when C < CUs, i.e. C <= 255
+constexpr int kXchMaxSlices = 16;                  // 4 granules per slice, one lane each: 64 lanes
+constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4;
+constexpr int kSyncTimeoutWord = 2 * kXchGranules;
+constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(2) + one poll: a few seconds
 
 struct ResPlan {
     int T, F4;            // threads per workgroup, float4 units per thread
@@ -1333,16 +1337,20 @@ struct ResPlan {
     FastDiv gqdiv;
     unsigned spin;        // bound of the exchange wait (kSpinLimit; tests shorten it)
     int drop;             // test hook: this slice never posts its ticket (-1 = none)
-    int stagger;          // s_sleep(4) rounds the second cohort of workgroups waits before loading (2 per CU)
-    int cohort;           // workgroups below this index are the first cohort
-    unsigned long long *trace;   // debug: [block][8] wall-clock stamps (100 MHz) of the kernel's phases, or nullptr
+    int xcd_map;          // slices of one channel are placed on workgroups with equal blockIdx % 8 (one XCD)
+    unsigned long long *trace;   // DEEPIPR_TRACE builds only: [block][8] wall-clock stamps of the kernel's phases
 };
 
 // Phase stamps of one workgroup (thread 0): 0 entry, 1 loads consumed + block sums done, 2 exchange done,
-// 3 channel table ready, 4 all stores issued.  deepipr_debug_trace() arms it; nullptr in production.
+// 3 channel table ready (forward), 4 all stores issued.  Compiled in only with -DDEEPIPR_TRACE (`make trace` builds
+// libdeepipr_hip_trace.so for tools/res_trace.py): the stamps cost registers, and k_bn_res_bwd<1024, 8> sits at the
+// 128-VGPR limit of four waves per SIMD -- with them it spills 100 B per lane to scratch (measured as +75 % HBM
+// traffic by the PMC passes of round 2).
 __device__ __forceinline__ void res_stamp(const ResPlan &pl, int slot) {
+#ifdef DEEPIPR_TRACE
     if (pl.trace && threadIdx.x == 0)
         pl.trace[static_cast<size_t>(blockIdx.x) * 8 + slot] = wall_clock64();
+#endif
 }
 
 __device__ __forceinline__ void sc1_store(double *p, double v) {
@@ -1389,52 +1397,98 @@ __device__ __forceinline__ void res_block_sums(double &a, double &b, const ResPl
     }
 }
 
-// In-launch exchange of one channel's two partial sums between its S slice workgroups (thread 0 only).
-// Hand-off form (MI355X_MICROARCH.md, "valid forms"): write-through (sc1) payload stores -> s_waitcnt vmcnt(0)
-// (inline asm: the compiler cannot drop it) -> agent-scope ticket; the reader polls the ticket with sc1 loads (they
-// bypass this CU's L1), then reads the payload with sc1 loads -- which may replace an agent acquire because the
-// producer stored sc1.  The compiler barriers keep the payload loads behind the poll in program order; the
-// hardware returns vector loads of one wave in order.
-// A wait that expires does NOT carry on with whatever the workspace holds: the statistics are poisoned with NaN
-// (every output of the layer, hence the loss, becomes NaN) and sync[kSyncTimeoutWord] is raised for the host.
-__device__ __forceinline__ void res_exchange(double &s0, double &s1, double *part, int C, int c, int s, int S,
-                                             unsigned *sync, int cb, unsigned spin_limit, int drop) {
-    sc1_store(part + (static_cast<size_t>(s) * 2 + 0) * C + c, s0);
-    sc1_store(part + (static_cast<size_t>(s) * 2 + 1) * C + c, s1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned ticket;
-    if (s == drop)                                     // test hook: a partner that never arrives
-        ticket = __hip_atomic_load(sync + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        ticket = __hip_atomic_fetch_add(sync + cb, 64u / static_cast<unsigned>(S), __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);     // relaxed: the payload is already written through
-    const unsigned target = (ticket & ~63u) + 64u;
-    unsigned spins = 0;
+// In-launch exchange of one channel's two partial sums (doubles) between its S slice workgroups, run by WAVE 0.
+//
+// Transport: data-tagged granules (MI355X_MICROARCH.md, hand-off price list: "handoff-1to1", the cheapest valid
+// form -- one naturally aligned 8-byte {payload, tag} written by ONE sc1 store needs no ordering at all, neither a
+// drained flag nor an agent fence).  A slice publishes its two doubles as four granules {32 payload bits, tag};
+// lane i of wave 0 then polls granule i of the channel (4*S <= 64 lanes) with sc1 loads until its tag is the
+// call's tag, and every lane sums the S partials in slice order from wave shuffles: all partners get bit-identical
+// statistics.  The first version of this kernel (round 1) used sc1 payload stores -> vmcnt(0) drain -> returning
+// ticket atomic -> poll -> payload loads: four dependent round trips, measured at 4.0-4.8 us of a 17.9 us launch
+// (profiles/r02_res_trace_*.log); this form has one store and (usually) one or two polls.
+//
+// Tag: a per-slot call counter kept in the granule itself.  A slice reads its OWN slot's old tag when the kernel
+// starts and publishes old + 1; the slots of one channel in one S-region are always used together, so all partners
+// compute the same tag without any host-side state (launch arguments are frozen in a replayed hipGraph) and without
+// ever resetting the buffer.  A slice that never arrives (test hook `drop`) or an expired wait leaves the tags out
+// of step for good: every later call on that channel times out too, until the host re-zeroes the buffer.
+// An expired wait poisons the statistics with NaN and raises sync[kSyncTimeoutWord].
+struct ResXch {
+    unsigned long long *gran;     // this channel's S * 4 granules
+    unsigned expect;              // tag of this call
+};
+
+__device__ __forceinline__ unsigned long long xch_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load ... sc1: bypasses L1
+}
+
+__device__ __forceinline__ int xch_region(int S) { return kXchChannels * (S - 2) * 4; }   // 2 + 4 + ... + S/2 = S - 2
+
+// Called by every thread at kernel entry (only wave 0 needs it; one L2 round trip hidden behind the bulk loads).
+__device__ __forceinline__ ResXch res_xch_begin(unsigned *sync, int c, int s, int S) {
+    ResXch x;
+    x.gran = reinterpret_cast<unsigned long long *>(sync) + xch_region(S) + static_cast<size_t>(c) * S * 4;
+    x.expect = 0;
+    if (threadIdx.x < kWave) x.expect = static_cast<unsigned>(xch_load(x.gran + s * 4) >> 32) + 1u;
+    return x;
+}
+
+__device__ __forceinline__ void res_exchange(double &s0, double &s1, const ResXch &x, int s, int S, unsigned *sync,
+                                             unsigned spin_limit, int drop) {
+    const int lane = threadIdx.x;                      // wave 0
+    const unsigned long long b0 = static_cast<unsigned long long>(__double_as_longlong(s0));
+    const unsigned long long b1 = static_cast<unsigned long long>(__double_as_longlong(s1));
+    if (lane < 4 && s != drop) {
+        const unsigned long long src = lane < 2 ? b0 : b1;
+        const unsigned long long half = (lane & 1) ? (src >> 32) : (src & 0xffffffffull);
+        __hip_atomic_store(x.gran + s * 4 + lane, (static_cast<unsigned long long>(x.expect) << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ONE 8-byte sc1 store
+    }
+    unsigned long long v = 0;
+    bool ok = lane >= 4 * S;
     bool expired = false;
-    while (static_cast<int>(__hip_atomic_load(sync + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(4);
+    unsigned spins = 0;
+    while (true) {
+        if (!ok) {
+            v = xch_load(x.gran + lane);
+            ok = static_cast<unsigned>(v >> 32) == x.expect;
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
         if (++spins > spin_limit) {
-            __hip_atomic_store(sync + kSyncTimeoutWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             expired = true;
             break;
         }
     }
-    asm volatile("" ::: "memory");                     // payload loads stay behind the poll
+    const unsigned pay = static_cast<unsigned>(v);
     double t0 = 0.0, t1 = 0.0;
-    for (int sp = 0; sp < S; ++sp) {
-        t0 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 0) * C + c);
-        t1 += sc1_load(part + (static_cast<size_t>(sp) * 2 + 1) * C + c);
+    for (int sp = 0; sp < S; ++sp) {                   // slice order: identical rounding in every partner
+        const unsigned long long lo0 = __shfl(pay, 4 * sp, kWave), hi0 = __shfl(pay, 4 * sp + 1, kWave);
+        const unsigned long long lo1 = __shfl(pay, 4 * sp + 2, kWave), hi1 = __shfl(pay, 4 * sp + 3, kWave);
+        t0 += __longlong_as_double(static_cast<long long>((hi0 << 32) | lo0));
+        t1 += __longlong_as_double(static_cast<long long>((hi1 << 32) | lo1));
     }
-    if (expired) t0 = t1 = __longlong_as_double(0x7ff8000000000000LL);
+    if (expired) {
+        if (lane == 0) __hip_atomic_store(sync + kSyncTimeoutWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t0 = t1 = __longlong_as_double(0x7ff8000000000000LL);
+    }
     s0 = t0;
     s1 = t1;
 }
 
-// Second cohort of workgroups (two per CU): wait `rounds` x s_sleep(4) before issuing loads, so that its read phase
-// follows the first cohort's and each cohort's reduce/exchange bubble is covered by the other's memory phase.
-__device__ __forceinline__ void res_stagger(const ResPlan &pl) {
-    if (pl.stagger > 0 && static_cast<int>(blockIdx.x) >= pl.cohort)
-        for (int i = 0; i < pl.stagger; ++i) __builtin_amdgcn_s_sleep(4);
+// blockIdx -> (channel group cb, slice s).  XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch order, used
+// for speed only), so the S slices of a channel are given indices with equal b % 8: their granules stay in one L2.
+__device__ __forceinline__ void res_block_coords(const ResPlan &pl, int &cb, int &s) {
+    const int b = blockIdx.x;
+    if (pl.xcd_map) {
+        const int span = 8 * pl.S, g = b / span, r = b - g * span;
+        s = r >> 3;
+        cb = g * 8 + (r & 7);
+    } else {
+        cb = b / pl.S;
+        s = b - cb * pl.S;
+    }
 }
 
 template <int T>
@@ -1468,7 +1522,7 @@ __device__ __forceinline__ void sign_loss_block_t(const float *__restrict__ gamm
 }
 
 template <int T, int F4>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
+__global__ __launch_bounds__(T) void k_bn_res_fwd(
     const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
     const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
     unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
@@ -1481,14 +1535,16 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
         return;
     }
     const int t = threadIdx.x;
-    const int cb = blockIdx.x / pl.S, s = blockIdx.x - cb * pl.S;
+    int cb, s;
+    res_block_coords(pl, cb, s);
     const int c0 = cb * pl.G;
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
+    ResXch xc{};
+    if (pl.S > 1) xc = res_xch_begin(sync, c0, s, pl.S);
     // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
     res_stamp(pl, 0);
-    res_stagger(pl);
     const float K = reinterpret_cast<const float *>(x)[static_cast<size_t>(c0 + c_local) * pl.q4 * 4];
     float4 v[F4];
     unsigned idx[F4];
@@ -1517,10 +1573,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_fwd(
     res_block_sums<T>(s1, s2, pl, c_local, red);
     res_stamp(pl, 1);
     if (pl.S > 1) {                                   // G == 1 here
-        if (t == 0) {
-            res_exchange(s1, s2, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
-            xch[0] = s1;
-            xch[1] = s2;
+        if (t < kWave) {
+            res_exchange(s1, s2, xc, s, pl.S, sync, pl.spin, pl.drop);
+            if (t == 0) {
+                xch[0] = s1;
+                xch[1] = s2;
+            }
         }
         __syncthreads();
         s1 = xch[0];
@@ -1592,20 +1650,22 @@ __device__ __forceinline__ void res_bwd_prep(float d, float xv, const float4 &ch
 }
 
 template <int T, int F4>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
+__global__ __launch_bounds__(T) void k_bn_res_bwd(
     const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
     float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, double *part, unsigned *sync, ResBwdArgs a) {
     constexpr int NW = T / kWave;
     __shared__ double red[2 * NW * 8];
     __shared__ double xch[2];
     const int t = threadIdx.x;
-    const int cb = blockIdx.x / pl.S, s = blockIdx.x - cb * pl.S;
+    int cb, s;
+    res_block_coords(pl, cb, s);
     const int c0 = cb * pl.G;
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    ResXch xc{};
+    if (pl.S > 1) xc = res_xch_begin(sync, c0, s, pl.S);
     res_stamp(pl, 0);
-    res_stagger(pl);
     const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
     float4 dz[F4], xh[F4];
     unsigned idx[F4];
@@ -1652,10 +1712,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_bn_res_bwd(
     res_block_sums<T>(ag, ab, pl, c_local, red);
     res_stamp(pl, 1);
     if (pl.S > 1) {
-        if (t == 0) {
-            res_exchange(ag, ab, part, C, c0, s, pl.S, sync, cb, pl.spin, pl.drop);
-            xch[0] = ag;
-            xch[1] = ab;
+        if (t < kWave) {
+            res_exchange(ag, ab, xc, s, pl.S, sync, pl.spin, pl.drop);
+            if (t == 0) {
+                xch[0] = ag;
+                xch[1] = ab;
+            }
         }
         __syncthreads();
         ag = xch[0];
@@ -2389,22 +2451,21 @@ int device_cu_count() {
 
 // Tuning / test knobs of the single-pass kernels (deepipr_debug_tune); defaults are the shipped configuration.
 struct ResTune {
-    std::atomic<int> wg2{0};          // 1: plan two 512-thread workgroups per CU instead of one of 1024
-    std::atomic<int> stagger{0};      // s_sleep(4) rounds the second cohort waits before its loads (wg2 only)
     std::atomic<int> split_full{0};   // 1: split channels over slices whenever they do not fill the chip (not just < half)
+    std::atomic<int> xcd_map{1};      // 0: slices of a channel on consecutive workgroups (round-1 placement)
     std::atomic<int> spin{static_cast<int>(kSpinLimit)};
-    std::atomic<int> drop{-1};        // test hook: slice that never posts its exchange ticket
-    std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace)
+    std::atomic<int> drop{-1};        // test hook: slice that never publishes its partial sums
+    std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace, DEEPIPR_TRACE builds)
 };
 ResTune g_tune;
 
-// Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread may keep at 4 waves per SIMD.
+// Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread of a 1024-thread workgroup may keep.
+// (Two 512-thread workgroups per CU, with or without a delayed second cohort, were measured slower on every
+// CIFAR-shape layer -- profiles/r02_res_tune_knob_sweep.log -- and are not planned for.)
 bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out) {
     if (g_resident_mode.load(std::memory_order_relaxed) == 0 || P % 4 != 0) return false;
     const int cus = device_cu_count();
     if (cus <= 0) return false;
-    const int per_cu = g_tune.wg2.load(std::memory_order_relaxed) ? 2 : 1;
-    const int cap = cus * per_cu;                                   // workgroups that are co-resident for certain
     const bool split_full = g_tune.split_full.load(std::memory_order_relaxed) != 0;
     ResPlan pl{};
     pl.q4 = P / 4;
@@ -2413,10 +2474,10 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         G = 8 / pl.q4;
         while (G > 1 && C % G != 0) G >>= 1;
     }
-    auto slices = [&](int cb) {                  // split channels only when they cover less than half the slots:
-        int S = 1;                               // 128 workgroups already stream as fast as 256 with the exchange
-        if (can_sync && (split_full ? cb < cap : cb * 2 < cap))
-            while (S < 64 && cb * (S * 2) <= cap && S * 2 <= N) S *= 2;
+    auto slices = [&](int cb) {                  // split channels only when they cover less than half the CUs
+        int S = 1;
+        if (can_sync && (split_full ? cb < cus : cb * 2 < cus))
+            while (S < kXchMaxSlices && cb * (S * 2) <= cus && S * 2 <= N) S *= 2;
         return S;
     };
     int S = slices(C / G);
@@ -2424,34 +2485,28 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         G = 1;
         S = slices(C);
     }
-    if (S > 1 && C > kSyncCounters) S = 1;
+    if (S > 1 && C > kXchChannels) S = 1;
     pl.G = G;
     pl.gq = G * pl.q4;
     pl.S = S;
     pl.nps = (N + S - 1) / S;
     pl.blocks = (C / G) * S;
     const long long units = static_cast<long long>(pl.nps) * pl.gq;
-    const int big_t = per_cu == 2 ? 512 : 1024;
-    pl.T = (S == 1 && units <= 8 * 256) ? 256 : big_t;
+    pl.T = (S == 1 && units <= 8 * 256) ? 256 : 1024;
     if (pl.blocks * 4 < cus) return false;                   // too few workgroups to be worth a single pass
+    const long long need = (units + pl.T - 1) / pl.T;
     static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    auto pick = [&](int T) {
-        const long long need = (units + T - 1) / T;
-        for (int f : steps)
-            if (f >= need && f <= (T == 256 ? 8 : max_f4)) return f;
-        return 0;
-    };
-    pl.F4 = pick(pl.T);
-    if (pl.F4 == 0 && pl.T == 512 && S == 1) {               // no exchange, no residency constraint: one big workgroup
-        pl.T = 1024;
-        pl.F4 = pick(1024);
-    }
+    pl.F4 = 0;
+    for (int f : steps)
+        if (f >= need && f <= (pl.T == 256 ? 8 : max_f4)) {
+            pl.F4 = f;
+            break;
+        }
     if (pl.F4 == 0) return false;
     pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
     pl.spin = static_cast<unsigned>(g_tune.spin.load(std::memory_order_relaxed));
     pl.drop = g_tune.drop.load(std::memory_order_relaxed);
-    pl.stagger = (per_cu == 2 && pl.blocks > cus) ? g_tune.stagger.load(std::memory_order_relaxed) : 0;
-    pl.cohort = cus;
+    pl.xcd_map = (S > 1 && (C / G) % 8 == 0 && g_tune.xcd_map.load(std::memory_order_relaxed)) ? 1 : 0;
     pl.trace = g_tune.trace.load(std::memory_order_relaxed);
     *out = pl;
     return true;
@@ -2479,12 +2534,6 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
     const int ws = with_sign ? 1 : 0;
     if (pl.T == 256) {
         DEEPIPR_RES_CASES(k_bn_res_fwd, 256, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
-    } else if (pl.T == 512 && pl.F4 == 12) {
-        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<512, 12>), grid, dim3(512), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
-    } else if (pl.T == 512 && pl.F4 == 16) {
-        DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<512, 16>), grid, dim3(512), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
-    } else if (pl.T == 512) {
-        DEEPIPR_RES_CASES(k_bn_res_fwd, 512, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4)
     } else if (pl.F4 == 12) {
         DEEPIPR_LAUNCH(prof, (k_bn_res_fwd<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, pl, f, part, sync, ws, sa, r4);
     } else if (pl.F4 == 16) {
@@ -2504,8 +2553,6 @@ int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx,
     float4 *o4 = reinterpret_cast<float4 *>(dx);
     if (pl.T == 256) {
         DEEPIPR_RES_CASES(k_bn_res_bwd, 256, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
-    } else if (pl.T == 512) {
-        DEEPIPR_RES_CASES(k_bn_res_bwd, 512, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
     } else {
         DEEPIPR_RES_CASES(k_bn_res_bwd, 1024, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
     }
@@ -2571,9 +2618,8 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
 int deepipr_debug_tune(const char *key, int value) {
     if (!key) return fail(DEEPIPR_EINVAL, "debug_tune: null key");
     const std::string k(key);
-    if (k == "wg2") g_tune.wg2.store(value != 0);
-    else if (k == "stagger") g_tune.stagger.store(value < 0 ? 0 : value);
-    else if (k == "split_full") g_tune.split_full.store(value != 0);
+    if (k == "split_full") g_tune.split_full.store(value != 0);
+    else if (k == "xcd_map") g_tune.xcd_map.store(value != 0);
     else if (k == "exchange_spin") g_tune.spin.store(value <= 0 ? static_cast<int>(kSpinLimit) : value);
     else if (k == "exchange_drop") g_tune.drop.store(value);
     else return fail(DEEPIPR_EINVAL, "debug_tune: unknown key '%s'", key);

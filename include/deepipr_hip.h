@@ -185,9 +185,10 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * x (backward: dy and x) once, forms the channel sums, and produces y (dx) from registers: 8 / 12 B per element
  * instead of 12 / 20, one launch instead of three (+ the gamma/beta GEMV, resp. the dW update, for layers with W).
  * Layers with fewer channels than the device has CUs split every channel over several workgroups, which exchange
- * their partial sums inside the launch through `sync`: DEEPIPR_SYNC_WORDS 32-bit words that are zero before their
- * first use, are owned by this library from then on (every call leaves the counters a multiple of 64) and are
- * not shared by calls that can run concurrently.  That form needs all its workgroups co-resident, so pass
+ * their partial sums inside the launch through `sync`: DEEPIPR_SYNC_WORDS 32-bit words (8-byte {payload, tag}
+ * granules, the tag being a per-slot call counter) that are zero before their first use, are owned by this library
+ * from then on (never reset, also not across hipGraph replays) and are not shared by calls that can run
+ * concurrently.  That form needs all its workgroups co-resident, so pass
  * sync == NULL whenever another kernel may occupy CUs of the device at the same time (e.g. a collective on a
  * second stream); channel-owning layers (C >= CUs) then still take the single pass, the others the 3-launch
  * form.  If a bounded in-kernel wait ever expires, word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero AND the
@@ -204,15 +205,16 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * 28 in two kernels).  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
  * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
  * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
-#define DEEPIPR_SYNC_WORDS (4096 + 16)
-#define DEEPIPR_SYNC_TIMEOUT_WORD 4096
+#define DEEPIPR_SYNC_WORDS (2 * 256 * 30 * 4 + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, + flags */
+#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * 256 * 30 * 4)
 int deepipr_set_resident(int mode);
-/* Tuning / test knobs of the single-pass kernels, process-wide: "wg2" (two 512-thread workgroups per CU),
- * "stagger" (s_sleep(4) rounds the second cohort of workgroups waits before loading), "split_full",
- * "exchange_spin" (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never
- * posts its ticket: forces the time-out path in tests; -1 = none). */
+/* Tuning / test knobs of the single-pass kernels, process-wide: "split_full" (split channels over workgroups
+ * whenever they do not fill the chip), "xcd_map" (0: round-1 placement of a channel's slices), "exchange_spin"
+ * (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never publishes its
+ * partial sums: forces the time-out path in tests; -1 = none). */
 int deepipr_debug_tune(const char *key, int value);
-/* Phase tracing of the single-pass kernels (measurement only): while device_buffer != NULL, thread 0 of every
+/* Phase tracing of the single-pass kernels (measurement only; effective in libdeepipr_hip_trace.so, `make trace`,
+ * a no-op in the production library): while device_buffer != NULL, thread 0 of every
  * workgroup of k_bn_res_fwd / _bwd writes five 100 MHz wall-clock stamps to device_buffer[block][8]: entry, loads
  * consumed + workgroup sums formed, exchange done, channel table ready, all stores issued.  The buffer needs
  * 8 * 8 bytes per workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */

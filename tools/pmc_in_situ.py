@@ -21,6 +21,8 @@ import sys
 def family(name):
     name = name.replace('void ', '').replace('(anonymous namespace)::', '')
     m = re.match(r'(k_[a-z0-9_]+)', name)
+    if m and m.group(1).startswith('k_sgd_momentum'):
+        return 'k_sgd'
     return m.group(1) if m else None
 
 
@@ -47,7 +49,7 @@ def main():
                'dispatches_fetch_pass': nf, 'dispatches_write_pass': nw}
         rec['total'] = round(rec['fetch'] + rec['write'], 1)
         k = kern.get(fam[2:])
-        if k and k.get('launches_per_step'):
+        if k and k.get('launches_per_step') and 'bytes_per_step' in k:
             rec['algorithmic'] = round(k['bytes_per_step'] / k['launches_per_step'], 1)
             if rec['algorithmic']:
                 rec['traffic_over_algorithmic'] = round(rec['total'] / rec['algorithmic'], 4)

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Where the time goes inside the register-resident single-pass kernels: per-workgroup wall-clock stamps
 (deepipr_debug_trace, 100 MHz) of the phases of k_bn_res_fwd / k_bn_res_bwd, next to the kernel duration from the
-per-dispatch HIP events.  GPU box only:  python tools/res_trace.py [N]"""
+per-dispatch HIP events.  Needs the measurement build of the library (the production build compiles the stamps out):
+
+    make -C deepipr_amd/csrc trace && DEEPIPR_LIB=deepipr_amd/csrc/libdeepipr_hip_trace.so python tools/res_trace.py [N]
+
+(In that build k_bn_res_bwd<1024, 8> spills 28 B per lane -- its phases are slightly stretched; forward is exact.)"""
 import ctypes
 import os
 import sys
@@ -22,6 +26,8 @@ TICK_US = 0.01                                                  # wall_clock64()
 def phases(buf, nblk):
     t = buf[:nblk * 8].view(nblk, 8).cpu().numpy().astype(np.int64)
     t = t[t[:, 0] > 0]
+    if t[:, 3].max() == 0:                       # backward has no separate table phase: stamp 3 := stamp 2
+        t[:, 3] = t[:, 2]
     t0 = t[:, 0].min()
     rel = (t[:, :5] - t0) * TICK_US
     d = np.diff(rel, axis=1)
@@ -66,6 +72,8 @@ def run(shape, reps=10):
     return res
 
 
+if 'trace' not in os.path.basename(_lib.LIB_PATH):
+    raise SystemExit('res_trace.py needs the measurement build: see the docstring')
 for shape in SHAPES:
     r = run(shape)
     mb = 4 * shape[0] * shape[1] * shape[2] * shape[3] / 1e6

@@ -13,11 +13,9 @@ from deepipr_amd.passport_ops import kernels as K              # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(N, 64, 32, 32), (N, 128, 16, 16), (N, 256, 8, 8), (N, 512, 4, 4), (4 * N, 512, 8, 8)]
 dev = torch.device('cuda:0')
-CONFIGS = [('base', {}), ('split_full', {'split_full': 1}), ('wg2', {'wg2': 1}),
-           ('wg2+full', {'wg2': 1, 'split_full': 1})]
-for st in (2, 4, 8, 16, 32, 64):
-    CONFIGS.append(('wg2+full st%d' % st, {'wg2': 1, 'split_full': 1, 'stagger': st}))
-    CONFIGS.append(('wg2 st%d' % st, {'wg2': 1, 'stagger': st}))
+CONFIGS = [('base', {}), ('xcd_map off', {'xcd_map': 0}), ('split_full', {'split_full': 1}),
+           ('split_full, xcd off', {'split_full': 1, 'xcd_map': 0})]
+KNOBS = {'split_full': 0, 'xcd_map': 1}
 
 
 def run(shape, tail, reps=30):
@@ -52,14 +50,14 @@ for tail in (False, True):
         fb, bb = (12.0, 24.0) if tail else (8.0, 12.0)
         print('%s %-20s %6.1f MB' % ('tail ' if tail else 'plain', shape, mb))
         for name, knobs in CONFIGS:
-            for k in ('wg2', 'split_full', 'stagger'):
-                _lib.debug_tune(k, knobs.get(k, 0))
+            for k, default in KNOBS.items():
+                _lib.debug_tune(k, knobs.get(k, default))
             try:
                 f, b = run(shape, tail)
-                print('    %-18s fwd %6.2f us (%5.2f TB/s)  bwd %6.2f us (%5.2f TB/s)' %
+                print('    %-20s fwd %6.2f us (%5.2f TB/s)  bwd %6.2f us (%5.2f TB/s)' %
                       (name, f, fb / 4 * mb / f, b, bb / 4 * mb / b))
             except (AssertionError, RuntimeError) as e:
-                print('    %-18s -- %s' % (name, str(e)[:80]))
-for k in ('wg2', 'split_full', 'stagger'):
-    _lib.debug_tune(k, 0)
+                print('    %-20s -- %s' % (name, str(e)[:80]))
+for k, default in KNOBS.items():
+    _lib.debug_tune(k, default)
 print('sync timeouts:', K.sync_timeouts())
