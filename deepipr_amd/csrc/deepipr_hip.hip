@@ -1528,7 +1528,6 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
     constexpr int NW = T / kWave;
     __shared__ double red[2 * NW * 8];
-    __shared__ float4 chan[8];
     __shared__ double xch[2];
     if (with_sign && static_cast<int>(blockIdx.x) == pl.blocks) {
         sign_loss_block_t<T>(gamma, sa, C, red);
@@ -1545,18 +1544,34 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     if (pl.S > 1) xc = res_xch_begin(sync, c0, s, pl.S);
     // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
     res_stamp(pl, 0);
+    // what the channel table needs besides the sums, loaded up front
+    const int c_mine = c0 + c_local;
+    const float g_pre = gamma[c_mine], b_pre = beta[c_mine];
+    const bool owner = s == 0 && t < pl.gq && t == c_local * pl.q4;           // one thread per channel
+    float rm_old = 0.0f, rv_old = 0.0f;
+    if (owner && f.running_mean) {
+        rm_old = f.running_mean[c_mine];
+        rv_old = f.running_var[c_mine];
+    }
     const float K = reinterpret_cast<const float *>(x)[static_cast<size_t>(c0 + c_local) * pl.q4 * 4];
+    // float4 index of unit j of this workgroup's slice; kept in registers for the write phase only while that is
+    // affordable (F4 <= 8): the F4 = 12 / 16 instances sit at the 128-VGPR limit and recompute it instead
+    constexpr bool kKeepIdx = F4 <= 8;
+    auto unit_index = [&](int j) {
+        const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
+        return static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
+    };
     float4 v[F4];
-    unsigned idx[F4];
+    unsigned idx[kKeepIdx ? F4 : 1];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
         v[k] = make_float4(K, K, K, K);                                // unused units contribute (K-K) = 0
-        idx[k] = 0;
+        if (kKeepIdx) idx[k] = 0;
         if (j < units) {
-            const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
-            idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
-            v[k] = x[idx[k]];
+            const unsigned i = unit_index(j);
+            if (kKeepIdx) idx[k] = i;
+            v[k] = x[i];
         }
     }
     float a0 = 0.0f, a1 = 0.0f;
@@ -1585,30 +1600,27 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
         s2 = xch[1];
     }
     res_stamp(pl, 2);
-    if (t < pl.gq && t == c_local * pl.q4) {          // one thread per local channel
-        const int c = c0 + c_local;
-        const double dmu = s1 * f.inv_m;                               // mean - K
-        double var = s2 * f.inv_m - dmu * dmu;
-        if (var < 0.0) var = 0.0;
-        const float mean = static_cast<float>(static_cast<double>(K) + dmu);
-        const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
-        const float g = gamma[c], bt = beta[c];
-        chan[c_local] = make_float4(mean, invstd, g, bt);
-        if (s == 0) {
-            if (f.running_mean) {
-                f.running_mean[c] = (1.0f - f.momentum) * f.running_mean[c] + f.momentum * mean;
-                f.running_var[c] = (1.0f - f.momentum) * f.running_var[c] +
-                                   f.momentum * static_cast<float>(var * f.unbias);
-            }
-            float4 *row = reinterpret_cast<float4 *>(f.tbl + static_cast<size_t>(c) * kTbl);
-            row[0] = make_float4(mean, invstd, g, bt);
-            row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // Every thread holds its channel's sums: each forms mean / invstd itself (f64, identical arithmetic in all of
+    // them) from values preloaded at kernel entry -- no LDS broadcast, no barrier and no global-load latency between
+    // the statistics and the write phase; the channel's owner thread also updates the running statistics and the
+    // table (stores nobody waits for).
+    const double dmu = s1 * f.inv_m;                                   // mean - K
+    double var = s2 * f.inv_m - dmu * dmu;
+    if (var < 0.0) var = 0.0;
+    const float mean = static_cast<float>(static_cast<double>(K) + dmu);
+    const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
+    const float4 ch = make_float4(mean, invstd, g_pre, b_pre);
+    if (owner) {
+        if (f.running_mean) {
+            f.running_mean[c_mine] = (1.0f - f.momentum) * rm_old + f.momentum * mean;
+            f.running_var[c_mine] = (1.0f - f.momentum) * rv_old + f.momentum * static_cast<float>(var * f.unbias);
         }
+        float4 *row = reinterpret_cast<float4 *>(f.tbl + static_cast<size_t>(c_mine) * kTbl);
+        row[0] = ch;
+        row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && t == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
-    __syncthreads();
     res_stamp(pl, 3);
-    const float4 ch = chan[c_local];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
@@ -1621,11 +1633,12 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
                 o = make_float4(bn_affine1<false>(v[k].x, ch), bn_affine1<false>(v[k].y, ch),
                                 bn_affine1<false>(v[k].z, ch), bn_affine1<false>(v[k].w, ch));
             }
+            const unsigned i = kKeepIdx ? idx[k] : unit_index(j);
             if (residual) {                          // the block's tail: relu(layer output + shortcut)
-                const float4 r = residual[idx[k]];
+                const float4 r = residual[i];
                 o = make_float4(relu1(o.x + r.x), relu1(o.y + r.y), relu1(o.z + r.z), relu1(o.w + r.w));
             }
-            y[idx[k]] = o;
+            y[i] = o;
         }
     }
     res_stamp(pl, 4);
@@ -2451,8 +2464,14 @@ int device_cu_count() {
 
 // Tuning / test knobs of the single-pass kernels (deepipr_debug_tune); defaults are the shipped configuration.
 struct ResTune {
-    std::atomic<int> split_full{0};   // 1: split channels over slices whenever they do not fill the chip (not just < half)
-    std::atomic<int> xcd_map{1};      // 0: slices of a channel on consecutive workgroups (round-1 placement)
+    // Measured per shape with tools/res_tune.py (profiles/r02_res_tune_granule_exchange.log):
+    //  * split_full = 1: with the granule exchange at ~1.2 us, splitting C = 128 layers over 2 workgroups per channel
+    //    (256 workgroups instead of 128) wins 3-12 %; it lost 0-10 % with the 4 us ticket exchange of round 1;
+    //  * xcd_map = 0: putting a channel's slices on one XCD helps the plain layers by 2 % (exchange locality) but
+    //    costs the tail-folded backward 9 % (31.2 -> 34.0 us): one XCD then streams addresses 8 MB apart through its
+    //    L2 instead of neighbouring channels.  Tails carry most of the bytes, so slices stay on consecutive workgroups.
+    std::atomic<int> split_full{1};   // split channels over slices whenever they do not fill the chip (0: only below half)
+    std::atomic<int> xcd_map{0};      // 1: slices of a channel on workgroups with equal blockIdx % 8
     std::atomic<int> spin{static_cast<int>(kSpinLimit)};
     std::atomic<int> drop{-1};        // test hook: slice that never publishes its partial sums
     std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace, DEEPIPR_TRACE builds)
@@ -2474,7 +2493,7 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         G = 8 / pl.q4;
         while (G > 1 && C % G != 0) G >>= 1;
     }
-    auto slices = [&](int cb) {                  // split channels only when they cover less than half the CUs
+    auto slices = [&](int cb) {                  // split channels over slices until the workgroups fill the chip
         int S = 1;
         if (can_sync && (split_full ? cb < cus : cb * 2 < cus))
             while (S < kXchMaxSlices && cb * (S * 2) <= cus && S * 2 <= N) S *= 2;

@@ -208,8 +208,9 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
 #define DEEPIPR_SYNC_WORDS (2 * 256 * 30 * 4 + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, + flags */
 #define DEEPIPR_SYNC_TIMEOUT_WORD (2 * 256 * 30 * 4)
 int deepipr_set_resident(int mode);
-/* Tuning / test knobs of the single-pass kernels, process-wide: "split_full" (split channels over workgroups
- * whenever they do not fill the chip), "xcd_map" (0: round-1 placement of a channel's slices), "exchange_spin"
+/* Tuning / test knobs of the single-pass kernels, process-wide: "split_full" (default 1: split channels over
+ * workgroups whenever they do not fill the chip; 0: only below half), "xcd_map" (default 0; 1: a channel's slices on
+ * workgroups with equal index % 8), "exchange_spin"
  * (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never publishes its
  * partial sums: forces the time-out path in tests; -1 = none). */
 int deepipr_debug_tune(const char *key, int value);

@@ -13,9 +13,9 @@ from deepipr_amd.passport_ops import kernels as K              # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(N, 64, 32, 32), (N, 128, 16, 16), (N, 256, 8, 8), (N, 512, 4, 4), (4 * N, 512, 8, 8)]
 dev = torch.device('cuda:0')
-CONFIGS = [('base', {}), ('xcd_map off', {'xcd_map': 0}), ('split_full', {'split_full': 1}),
-           ('split_full, xcd off', {'split_full': 1, 'xcd_map': 0})]
-KNOBS = {'split_full': 0, 'xcd_map': 1}
+CONFIGS = [('default', {}), ('xcd_map on', {'xcd_map': 1}), ('split below half only', {'split_full': 0}),
+           ('below half, xcd on', {'split_full': 0, 'xcd_map': 1})]
+KNOBS = {'split_full': 1, 'xcd_map': 0}
 
 
 def run(shape, tail, reps=30):
@@ -48,16 +48,16 @@ for tail in (False, True):
     for shape in SHAPES:
         mb = 4 * shape[0] * shape[1] * shape[2] * shape[3] / 1e6
         fb, bb = (12.0, 24.0) if tail else (8.0, 12.0)
-        print('%s %-20s %6.1f MB' % ('tail ' if tail else 'plain', shape, mb))
+        print('%s %-22s %6.1f MB' % ('tail ' if tail else 'plain', shape, mb))
         for name, knobs in CONFIGS:
             for k, default in KNOBS.items():
                 _lib.debug_tune(k, knobs.get(k, default))
             try:
                 f, b = run(shape, tail)
-                print('    %-20s fwd %6.2f us (%5.2f TB/s)  bwd %6.2f us (%5.2f TB/s)' %
+                print('    %-22s fwd %6.2f us (%5.2f TB/s)  bwd %6.2f us (%5.2f TB/s)' %
                       (name, f, fb / 4 * mb / f, b, bb / 4 * mb / b))
             except (AssertionError, RuntimeError) as e:
-                print('    %-20s -- %s' % (name, str(e)[:80]))
+                print('    %-22s -- %s' % (name, str(e)[:80]))
 for k, default in KNOBS.items():
     _lib.debug_tune(k, default)
 print('sync timeouts:', K.sync_timeouts())
