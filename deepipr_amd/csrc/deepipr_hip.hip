@@ -1561,17 +1561,23 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
         const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
         return static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
     };
+    // the shortcut of a folded residual tail is fetched in the SAME load phase (while registers allow): read after
+    // the statistics it would be a second, latency-bound load phase in front of the stores
+    constexpr bool kPreRes = F4 <= 8;
     float4 v[F4];
+    float4 rs[kPreRes ? F4 : 1];
     unsigned idx[kKeepIdx ? F4 : 1];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
         v[k] = make_float4(K, K, K, K);                                // unused units contribute (K-K) = 0
         if (kKeepIdx) idx[k] = 0;
+        if (kPreRes) rs[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (j < units) {
             const unsigned i = unit_index(j);
             if (kKeepIdx) idx[k] = i;
             v[k] = x[i];
+            if (kPreRes && residual) rs[k] = residual[i];
         }
     }
     float a0 = 0.0f, a1 = 0.0f;
@@ -1635,7 +1641,7 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
             }
             const unsigned i = kKeepIdx ? idx[k] : unit_index(j);
             if (residual) {                          // the block's tail: relu(layer output + shortcut)
-                const float4 r = residual[i];
+                const float4 r = kPreRes ? rs[k] : residual[i];
                 o = make_float4(relu1(o.x + r.x), relu1(o.y + r.y), relu1(o.z + r.z), relu1(o.w + r.w));
             }
             y[i] = o;
@@ -2472,6 +2478,7 @@ struct ResTune {
     //    L2 instead of neighbouring channels.  Tails carry most of the bytes, so slices stay on consecutive workgroups.
     std::atomic<int> split_full{1};   // split channels over slices whenever they do not fill the chip (0: only below half)
     std::atomic<int> xcd_map{0};      // 1: slices of a channel on workgroups with equal blockIdx % 8
+    std::atomic<int> small_t{1};      // 256-thread workgroups for slices of <= 2048 float4 (0: always 1024 threads)
     std::atomic<int> spin{static_cast<int>(kSpinLimit)};
     std::atomic<int> drop{-1};        // test hook: slice that never publishes its partial sums
     std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace, DEEPIPR_TRACE builds)
@@ -2511,7 +2518,7 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     pl.nps = (N + S - 1) / S;
     pl.blocks = (C / G) * S;
     const long long units = static_cast<long long>(pl.nps) * pl.gq;
-    pl.T = (S == 1 && units <= 8 * 256) ? 256 : 1024;
+    pl.T = (S == 1 && units <= 8 * 256 && g_tune.small_t.load(std::memory_order_relaxed)) ? 256 : 1024;
     if (pl.blocks * 4 < cus) return false;                   // too few workgroups to be worth a single pass
     const long long need = (units + pl.T - 1) / pl.T;
     static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -2639,6 +2646,7 @@ int deepipr_debug_tune(const char *key, int value) {
     const std::string k(key);
     if (k == "split_full") g_tune.split_full.store(value != 0);
     else if (k == "xcd_map") g_tune.xcd_map.store(value != 0);
+    else if (k == "small_t") g_tune.small_t.store(value != 0);
     else if (k == "exchange_spin") g_tune.spin.store(value <= 0 ? static_cast<int>(kSpinLimit) : value);
     else if (k == "exchange_drop") g_tune.drop.store(value);
     else return fail(DEEPIPR_EINVAL, "debug_tune: unknown key '%s'", key);

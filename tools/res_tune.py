@@ -14,8 +14,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(N, 64, 32, 32), (N, 128, 16, 16), (N, 256, 8, 8), (N, 512, 4, 4), (4 * N, 512, 8, 8)]
 dev = torch.device('cuda:0')
 CONFIGS = [('default', {}), ('xcd_map on', {'xcd_map': 1}), ('split below half only', {'split_full': 0}),
-           ('below half, xcd on', {'split_full': 0, 'xcd_map': 1})]
-KNOBS = {'split_full': 1, 'xcd_map': 0}
+           ('always 1024 threads', {'small_t': 0})]
+KNOBS = {'split_full': 1, 'xcd_map': 0, 'small_t': 1}
 
 
 def run(shape, tail, reps=30):
