@@ -197,6 +197,42 @@ def test_trainable_keys_match_reference_autograd_on_gpu(K, name, golden_dir):
         close(v, gold['dkey/%s/%s' % (name, k)], k, 1e-4, 1e-5)
 
 
+# ----------------------------------------------------------------------------- adversarial signature rows
+def test_signature_bits_on_adversarial_near_zero_rows(K, golden_dir):
+    """Rows of W tuned so that the exact gamma is +-1e-2 ... +-1e-8 (the smallest far below the fp32 summation noise
+    of the 144-term dot product), evaluated by the REFERENCE's own get_scale (goldens blocks.npz: nearzero/*,
+    passportconv2d.py:142-158).  The kernel accumulates in f64 and rounds once, so
+      * its sign(gamma) is the sign of the exact sum on EVERY row, and
+      * it equals the reference's sign and value wherever the reference's own fp32 answer is numerically meaningful
+        (|gamma| above 8 eps * sum|W_k m_k|); below that bound the reference itself flips 12 of the 96 signs relative
+        to the exact sum, which no implementation can or should reproduce."""
+    from oracle import np_passport as npp
+    gold = load_golden(golden_dir, 'blocks')
+    w, skey, key, g_ref = (gold['nearzero/' + k] for k in ('w', 'skey', 'key', 'gamma_ref'))
+    co = w.shape[0]
+    s, n = npp.pooled_patch_sum(skey.astype(np.float64), 3, 3, 1, 1)
+    exact = w.reshape(co, -1).astype(np.float64) @ (s / n)
+    bound = 8 * 6e-8 * (np.abs(w.reshape(co, -1).astype(np.float64)) * np.abs(s / n)).sum(axis=1)
+    m = K.pooled_patch_mean(dev(np.stack([skey, key])), 3, 3, 1, 1)
+    gamma = host(K.gamma_beta_fwd(dev(w), m)[0])
+    assert np.array_equal(np.sign(gamma), np.sign(exact)), 'sign of the exact sum, every row'
+    assert np.all(np.abs(gamma - exact) <= 1.2e-7 * np.abs(exact) + 1e-30)           # one rounding of the exact value
+    meaningful = np.abs(exact) >= bound
+    assert meaningful.sum() >= 40 and (~meaningful).sum() >= 20                     # the fixture spans both regimes
+    assert np.array_equal(np.sign(gamma[meaningful]), np.sign(g_ref[meaningful]))
+    assert np.all(np.abs(gamma - g_ref)[meaningful] <= bound[meaningful])
+    # and the layer API reads the same bits out (TesterPrivate.test_signature path)
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    blk = PassportBlock(w.shape[1], co, 3, 1, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.1})
+    with torch.no_grad():
+        blk.weight.copy_(torch.from_numpy(w))
+    blk = blk.to(DEV)
+    blk.set_key(dev(key), dev(skey))
+    with torch.no_grad():
+        bits = host(blk.get_scale().view(-1).sign())
+    assert np.array_equal(bits, np.sign(exact))
+
+
 # ----------------------------------------------------------------------------- one layer, whole backward chain
 @pytest.mark.miopen_pinned
 @pytest.mark.parametrize('fuse_norm', [True, False])

@@ -207,7 +207,40 @@ def block_cases():
     out['selection/set_key_key'] = blk.key.numpy().copy()
     out['selection/set_key_skey'] = blk.skey.numpy().copy()
     out.update(dkey_cases())
+    out.update(nearzero_case())
     return out
+
+
+def nearzero_case():
+    """Adversarial signature rows: weights tuned so that the EXACT gamma of each output channel is a prescribed tiny
+    value (down to 1e-8, far below fp32 summation noise of a 144-term dot product), then evaluated by the reference's
+    own get_scale (fp32 oneDNN conv + means, passportconv2d.py:142-158).  The fixture carries the inputs (small) and
+    the reference's gamma; the tests check that the kernels' sign(gamma) equals the reference's wherever the
+    reference's own answer is numerically meaningful, and the exact sign everywhere."""
+    from oracle import np_passport as npp
+    rs = np.random.RandomState(21)
+    co, ci, hw = 96, 16, 6
+    w = (rs.standard_normal((co, ci, 3, 3)) * 0.2).astype(np.float32)
+    skey = rs.uniform(-1, 1, (1, ci, hw, hw)).astype(np.float32)
+    key = rs.uniform(-1, 1, (1, ci, hw, hw)).astype(np.float32)
+    s, n = npp.pooled_patch_sum(skey.astype(np.float64), 3, 3, 1, 1)
+    m = s / n                                                   # [K] f64, K = ci*9
+    k0 = 4                                                      # centre tap of input channel 0
+    mags = [1e-2, 1e-4, 1e-5, 1e-6, 3e-7, 1e-7, 3e-8, 1e-8]
+    wf = w.reshape(co, -1).astype(np.float64)
+    for c in range(co):
+        target = mags[c % len(mags)] * (1.0 if (c // len(mags)) % 2 == 0 else -1.0)
+        g = wf[c] @ m
+        wf[c, k0] -= (g - target) / m[k0]
+    w = wf.astype(np.float32).reshape(co, ci, 3, 3)
+    torch.manual_seed(0)
+    blk = PassportBlock(ci, co, 3, 1, 1, {'norm_type': 'none', 'key_type': 'random', 'sign_loss': 0.1})
+    with torch.no_grad():
+        blk.weight.copy_(torch.from_numpy(w))
+    blk.set_key(torch.from_numpy(key), torch.from_numpy(skey))
+    with torch.no_grad():
+        gamma = blk.get_scale().view(-1).numpy().copy()
+    return {'nearzero/w': w, 'nearzero/skey': skey, 'nearzero/key': key, 'nearzero/gamma_ref': gamma}
 
 
 def dkey_cases():

@@ -14,3 +14,4 @@ run bench_v2_eager.json --scheme 2 --classes 100 --batch 32 --steps 100 --warmup
 run bench_v2_graph.json --scheme 2 --classes 100 --batch 32 --steps 100 --warmup 20 --no-stress --no-cpu-baseline
 run bench_imagenet.json --image-size 224 --classes 1000 --batch 128 --steps 20 --warmup 5 --no-stress --no-cpu-baseline
 run bench_r50.json --arch resnet50 --image-size 224 --classes 1000 --batch 64 --steps 20 --warmup 5 --no-stress --no-cpu-baseline
+run bench_r50_bs256.json --arch resnet50 --image-size 224 --classes 1000 --batch 256 --steps 10 --warmup 3 --no-stress --no-cpu-baseline
