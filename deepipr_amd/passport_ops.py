@@ -678,8 +678,12 @@ class _PassportBNLayer(torch.autograd.Function):
         dres = out[4] if ctx.tail else None
         if in_node_conv:
             need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-            dx, dw, _ = torch.ops.aten.convolution_backward(
-                dx, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
+            if need_dx or need_dw:
+                dx, dw, _ = torch.ops.aten.convolution_backward(
+                    dx, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                    [need_dx, need_dw, False])
+            else:                                         # frozen first layer: nothing flows further
+                dx = dw = None
             if need_dw:
                 dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw.contiguous())
         dsk = dk = None

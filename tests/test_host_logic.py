@@ -495,3 +495,22 @@ def test_flat_sgd_device_hypers_follow_the_scheduler(cpu_kernels):
     opt.step()
     assert torch.allclose(lin.weight, w0 - 0.5 - 0.05)
     assert opt._hyper.tolist() == pytest.approx([0.05, 0.0, 0.0, 1.0])
+
+
+def test_conv_inside_node_with_frozen_weight_and_input(cpu_kernels):
+    """The fused conv + passport node when neither the input nor the weight needs a gradient (a frozen first layer, the
+    fine-tuning set-ups of the reference's transfer-learning harness): backward must not call convolution_backward
+    with an all-false mask, gradients still reach trainable keys."""
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    torch.manual_seed(8)
+    np.random.seed(8)
+    blk = PassportBlock(4, 16, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1})
+    x = torch.randn(3, 4, 6, 6)
+    blk(x)                                                  # draws the keys
+    blk.weight.requires_grad_(False)
+    key = blk.key.clone()
+    del blk.key
+    blk.register_parameter('key', torch.nn.Parameter(key))
+    y = blk(x)
+    (y.sum() + blk.sign_loss.loss).backward()
+    assert blk.weight.grad is None and blk.key.grad is not None and torch.isfinite(blk.key.grad).all()
