@@ -17,7 +17,7 @@
 //     combines go through LDS, cross-workgroup combines are fixed-order partial sums (no float atomics):
 //     bit-reproducible.  They are finished in the prologue of the NEXT kernel, except in the
 //     register-resident single-pass kernels (k_bn_res_*), where the few workgroups of one channel exchange
-//     two doubles inside the launch (write-through stores + a relaxed agent-scope ticket, bounded wait).
+//     two doubles inside the launch (self-validating 8-byte {payload, tag} granules, sc1 stores / loads, bounded wait).
 //   * 16 B per lane (float4) global accesses wherever the plane size allows; streaming grids are sized to
 //     >= 4 workgroups per CU (256 CUs) and capped at 2048 with grid-stride loops; the resident kernels use
 //     one 1024-thread workgroup per CU and keep the layer's activations in the 128 MB register file.
@@ -1311,14 +1311,12 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 //   * workgroup = (channel group cb, batch slice s): G adjacent channels (G > 1 only for planes shorter than a
 //     128-byte line) x `nps` samples; thread t keeps float4 units t, t+T, ... (F4 of them, a template constant);
 //   * S == 1: the workgroup owns its channels outright, nothing leaves the CU between the two phases;
-//   * S > 1 (fewer channels than CUs): the S workgroups of a channel exchange their two partial sums in-launch:
-//     write-through (sc1) stores -> vmcnt drain -> relaxed agent-scope ticket on sync[cb]; one lane polls the
-//     ticket word relaxed and reads the S partials back with sc1 loads, summed in slice order (every partner
-//     gets bit-identical statistics).  Each call adds exactly 64 to sync[cb] (each slice adds 64/S), so the word
-//     needs no reset: it only has to be a multiple of 64 -- zero once -- when a call starts.  All S*CB workgroups
-//     must be co-resident: the host only takes this path with T = 1024 and a grid <= the CU count, on a device it
-//     does not share with a concurrent kernel (the caller withholds `sync` otherwise); the spin is bounded and
-//     reports through sync[kSyncTimeoutWord].
+//   * S > 1 (fewer channels than CUs): the S workgroups of a channel exchange their two partial sums in-launch as
+//     data-tagged granules (res_exchange below), summed in slice order: every partner gets bit-identical
+//     statistics.  All S*CB workgroups must be co-resident: the host only takes this path with T = 1024 and a
+//     grid <= the CU count, on a device it does not share with a concurrent kernel (the caller withholds `sync`
+//     otherwise); the wait is bounded, an expired one poisons the statistics with NaN and raises
+//     sync[kSyncTimeoutWord].
 // Fixed-order sums throughout: bit-reproducible run to run.
 // ============================================================================================
 // Exchange buffer (`sync`, DEEPIPR_SYNC_WORDS 32-bit words = granules of 8 bytes): for every slice count S in
@@ -1336,7 +1334,7 @@ struct ResPlan {
     int blocks;           // (C/G) * S
     FastDiv gqdiv;
     unsigned spin;        // bound of the exchange wait (kSpinLimit; tests shorten it)
-    int drop;             // test hook: this slice never posts its ticket (-1 = none)
+    int drop;             // test hook: this slice never publishes its partial sums (-1 = none)
     int xcd_map;          // slices of one channel are placed on workgroups with equal blockIdx % 8 (one XCD)
     unsigned long long *trace;   // DEEPIPR_TRACE builds only: [block][8] wall-clock stamps of the kernel's phases
 };
