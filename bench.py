@@ -223,7 +223,13 @@ def main():
     ap.add_argument('--eager', action='store_true', help='eager dispatch of the timed region (exchange overlapped with backward)')
     ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
     ap.add_argument('--ddp-static-graph', type=int, default=1, help='DistributedDataParallel(static_graph=...)')
+    ap.add_argument('--verbose', action='store_true', help='phase progress with timestamps on stderr')
     args = ap.parse_args()
+    t_start = time.perf_counter()
+
+    def note(msg):
+        if args.verbose:
+            print('bench.py [%7.1f s] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     rank, local_rank, world = D.init_from_env()
     if world != args.gpus:
@@ -236,6 +242,7 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find-mode, as train_v1.py:8
 
     model = build_model(args, device)
+    note('model built')
     if args.no_fuse:
         for mod in model.modules():
             if hasattr(mod, 'fuse_norm'):
@@ -267,7 +274,10 @@ def main():
         net = wrap(DualBranch(model))
         step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
 
+    note('keys drawn, state broadcast, optimiser built')
     all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
+    torch.cuda.synchronize()
+    note('first eager step done (MIOpen find / kernel selection for every conv shape)')
     # Launch mode of the timed region: hipGraph replay by default.  The step issues ~260 dispatches (~500 for the
     # dual-forward V2/V3 step); eager enqueue costs 4.5-9 ms of host time against 5.1-5.6 ms of GPU time, so an eager
     # step is host-bound exactly where it matters most (32 images per GPU in config P).
@@ -294,8 +304,11 @@ def main():
             use_graph, step = False, eager_step
     import torch.distributed as _td
     tdist_on = _td.is_available() and _td.is_initialized()
+    note('launch mode: %s' % ('hipGraph replay' if use_graph else 'eager'))
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    note('warm-up done')
     timing = not args.no_kernel_timing
     D.barrier()
     torch.cuda.synchronize()
@@ -318,6 +331,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
+    note('timed region done: %.3f ms per step' % (1000.0 * dt / args.steps))
     sampled = len(range(0, args.steps, stride))
     if timing and use_graph:
         sampled = min(args.steps, 30)
