@@ -45,6 +45,10 @@ CASES = {
     'resnet18_v1_wm': dict(arch='resnet18', scheme=1, norm='bn', ncls=10, n=4, config=resnet18_config(), wm=True),
     'resnet18_v2':   dict(arch='resnet18', scheme=2, norm='bn', ncls=100, n=4, config=resnet18_config()),
     'resnet18_v3':   dict(arch='resnet18', scheme=3, norm='bn', ncls=100, n=6, config=resnet18_config(), wm=True),
+    # the other norm types at ResNet shapes (models/layers/passportconv2d.py:59-62: GroupNorm(o // 16, o) /
+    # InstanceNorm2d(o), both affine=False, inside the passport layers; affine GroupNorm / InstanceNorm ConvBlocks)
+    'resnet18_v1_gn': dict(arch='resnet18', scheme=1, norm='gn', ncls=10, n=4, config=resnet18_config()),
+    'resnet18_v2_in': dict(arch='resnet18', scheme=2, norm='in', ncls=100, n=4, config=resnet18_config()),
     # ImageNet geometry: num_classes == 1000 switches the 7x7/2 stem + 3x3/2 max-pool on
     # (models/resnet_passport.py:94-98); 3x224x224 inputs, layer4 passports act on 7x7 maps
     'resnet18_v1_imagenet': dict(arch='resnet18', scheme=1, norm='bn', ncls=1000, n=2, hw=224,
