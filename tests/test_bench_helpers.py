@@ -1,0 +1,34 @@
+"""bench.py's host-side helpers (no GPU): the PMC traffic record is quoted only for the launch mix it was measured
+on, and the committed record describes the default workload."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pmc_traffic_is_quoted_only_for_the_same_launch_mix():
+    bench = _bench()
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_bn_res_bwd']['in_situ_per_launch']
+    alg = rec['algorithmic']
+    assert bench.pmc_traffic('k_bn_res_bwd', 'in_situ_per_launch', alg) == int(rec['fetch'] + rec['write'])
+    assert bench.pmc_traffic('k_bn_res_bwd', 'in_situ_per_launch', alg * 1.005) is not None     # same mix, rounding
+    assert bench.pmc_traffic('k_bn_res_bwd', 'in_situ_per_launch', alg * 1.2) is None           # another mix
+    assert bench.pmc_traffic('k_no_such_kernel', 'in_situ_per_launch', alg) is None
+    assert bench.pmc_traffic('k_bn_res_bwd', 'no_such_shape', alg) is None
+    # the single pass moves every byte once: measured traffic within 2 % of the algorithmic bytes
+    assert abs((rec['fetch'] + rec['write']) / alg - 1.0) < 0.02
+    # config R, batch 128: 20 launches per step, 1 317 011 456 algorithmic bytes per step
+    assert abs(alg * 20 - 1317011456) < 1024
+
+
+def test_host_cores_is_positive_and_bounded():
+    bench = _bench()
+    assert 1 <= bench.host_cores() <= 32
