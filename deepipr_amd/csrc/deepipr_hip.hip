@@ -1708,6 +1708,9 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
                                 o.w > 0.0f ? d.w : 0.0f);
                 a.dres[idx[k]] = d;
                 dz[k] = d;
+            } else if (a.dy2) {                     // two consumers, no tail (the stem): their gradients summed here
+                const float4 e = a.dy2[idx[k]];
+                dz[k] = make_float4(dz[k].x + e.x, dz[k].y + e.y, dz[k].z + e.z, dz[k].w + e.w);
             }
         }
     }
@@ -2571,7 +2574,7 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
 int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
                    const ResPlan &pl, double *part, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
-    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : 12.0) * static_cast<double>(N) * C * pl.q4 * 4;
+    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : (a.dy2 ? 16.0 : 12.0)) * static_cast<double>(N) * C * pl.q4 * 4;
     const dim3 grid(pl.blocks);
     const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *o4 = reinterpret_cast<float4 *>(dx);
@@ -2788,8 +2791,8 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                             float *dx, float *dW, float *dgamma, float *dbeta, float *table_out, void *workspace,
                             unsigned int *sync, const float *dy2, const float *tail_out, float *dres,
                             void *stream) {
-    if ((tail_out != nullptr) != (dres != nullptr) || (dy2 && !tail_out))
-        return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tail_out and dres go together (dy2 only with them)");
+    if ((tail_out != nullptr) != (dres != nullptr))
+        return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tail_out and dres go together");
     if ((tail_out && !aligned16(tail_out)) || (dres && !aligned16(dres)) || (dy2 && !aligned16(dy2)))
         return fail(DEEPIPR_EINVAL, "passport_bn_bwd: tail pointers must be 16-byte aligned");
     if (!dy || !x || !table || !dx || !dgamma || !dbeta || !table_out || !workspace || bad_dims(N, C, HW))
@@ -2811,9 +2814,9 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
         if (rc != DEEPIPR_OK) return rc;
         return dW ? deepipr_gamma_beta_bwd(dgamma, dbeta, m, C, K, dW, stream) : DEEPIPR_OK;
     }
-    if (tail_out)
-        return fail(DEEPIPR_EUNSUPPORTED, "passport_bn_bwd: the fused residual tail needs the single-pass form "
-                                          "(ask deepipr_passport_bn_resident first)");
+    if (tail_out || dy2)
+        return fail(DEEPIPR_EUNSUPPORTED, "passport_bn_bwd: the fused residual tail / a second gradient (dy2) needs the "
+                                          "single-pass form (ask deepipr_passport_bn_resident first)");
     BwdPlan pl;
     int rc = launch_walk<WALK_BN_BWD>(dy, x, table, part, N, C, HW, relu, &pl, st);
     if (rc != DEEPIPR_OK) return rc;

@@ -33,10 +33,12 @@ def reset_sign_losses(model):
 
 
 def total_sign_loss(model, device):
-    total = torch.zeros((), device=device)
+    """Sum of the SignLoss modules' losses (trainer.py:140-142) -- without a zero-filled start value and its extra add."""
+    total = None
     for m in sign_loss_modules(model):
-        total = total + m.loss
-    return total
+        if isinstance(m.loss, torch.Tensor):
+            total = m.loss if total is None else total + m.loss
+    return total if total is not None else torch.zeros((), device=device)
 
 
 def mean_sign_acc(model, device):

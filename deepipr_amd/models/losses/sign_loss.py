@@ -5,6 +5,14 @@ import torch.nn as nn
 from deepipr_amd import passport_ops as P
 
 
+def _plus(cur, new):
+    """cur + new, without a kernel launch for the first term after reset() (0 + x is x): `loss += ...` on the freshly
+    reset meters cost two tiny ATen kernels per passport layer and step (models/losses/sign_loss.py:52-54)."""
+    if isinstance(cur, (int, float)) and cur == 0:
+        return new
+    return cur + new
+
+
 class SignLoss(nn.Module):
     def __init__(self, alpha, b=None):
         super().__init__()
@@ -34,14 +42,14 @@ class SignLoss(nn.Module):
         """loss += hinge + 1e-5*sum(gamma^2); acc += sign accuracy -- sign_loss.py:32-54 (one launch)."""
         self.scale_cache = scale
         loss, acc, _ = P.sign_loss(scale.reshape(-1), self.b, self.alpha, P.L2)
-        self.loss = self.loss + loss
-        self.acc = self.acc + acc
+        self.loss = _plus(self.loss, loss)
+        self.acc = _plus(self.acc, acc)
 
     def add_fused(self, scale, loss, acc):
         """Account for values the fused passport-layer launch already produced."""
         self.scale_cache = scale
-        self.loss = self.loss + loss
-        self.acc = self.acc + acc
+        self.loss = _plus(self.loss, loss)
+        self.acc = _plus(self.acc, acc)
 
     def reset(self):
         self.loss = 0

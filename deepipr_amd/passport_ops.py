@@ -663,7 +663,10 @@ class _PassportBNLayer(torch.autograd.Function):
         if dy is None:
             dy = torch.zeros_like(x)
         if dy2 is not None and not ctx.tail:
-            dy, dy2 = dy + dy2, None
+            n_, c_ = x.shape[0], x.shape[1]
+            if not (kernels.bn_resident(n_, c_, x.numel() // (n_ * c_)) & 2):
+                dy, dy2 = dy + dy2, None                    # 3-launch form: the two gradients are added here
+            # else: the single-pass backward sums them itself (deepipr_passport_bn_bwd, dy2 without tail_out)
         dl = None if (bb is None or dloss is None) else dloss.contiguous()
         if w is None:
             dgamma_extra = dbeta_extra = None

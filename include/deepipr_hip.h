@@ -202,7 +202,9 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * written).  backward: tail_out = that `out`, dy (+ optional dy2: `out` has two consumers, see
  * deepipr_relu_bwd2) the gradient w.r.t. it; the kernel forms d = (dy + dy2) * [tail_out > 0], writes it to dres
  * (the shortcut's gradient) and continues with d as the layer's upstream gradient (20-24 B/element instead of
- * 28 in two kernels).  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
+ * 28 in two kernels).  dy2 without tail_out (single-pass form only): the layer's output simply has two consumers
+ * (the stem feeds layer1's first conv and its identity shortcut); the upstream gradient is dy + dy2, summed in the
+ * kernel (16 B/element) instead of by a separate add pass.  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
  * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
  * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
 #define DEEPIPR_SYNC_WORDS (2 * 256 * 30 * 4 + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, + flags */

@@ -131,6 +131,8 @@ class OracleKernels:
             d = dy.detach() if dy2 is None else dy.detach() + dy2.detach()
             dres = torch.where(tail_out > 0, d, torch.zeros_like(d))
             dy = dres
+        elif dy2 is not None:                 # two consumers, no tail: the gradients are summed by the kernel
+            dy = dy.detach() + dy2.detach()
         x64, dy64 = x.detach().double(), dy.detach().double()
         xh = (x64 - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
         z32 = npp.affine_relu_fwd(xh.float().numpy(), table[:, 2].numpy(), table[:, 3].numpy(), False)

@@ -314,6 +314,26 @@ def test_gamma_beta_bwd_accumulates_into_an_existing_wgrad(K, co, kk):
     assert torch.equal(acc, base + fresh)                      # one rounding of the same sum
 
 
+# ----------------------------------------------------------------------------- two consumers, no tail
+@pytest.mark.parametrize('shape', [(128, 64, 32, 32), (128, 128, 16, 16), (128, 512, 4, 4), (33, 256, 8, 8)])
+def test_single_pass_backward_sums_two_incoming_gradients(K, shape):
+    """dy2 without tail_out (the stem's output feeds layer1's first conv and its identity shortcut): the single-pass
+    backward forms dy + dy2 itself; bit-identical to adding them first (one fp32 add either way)."""
+    n, c, h, w = shape
+    rs = np.random.RandomState(n + c)
+    x, dy, dy2 = (dev(rs.standard_normal(shape)) for _ in range(3))
+    g, b = dev(1 + 0.3 * rs.standard_normal(c)), dev(0.2 * rs.standard_normal(c))
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    assert K.bn_resident(n, c, h * w) & 2
+    out = K.passport_bn_fwd(x, None, None, g, b, None, 0.0, True, rm, rv, None, 0.1, 1e-5, True)
+    a = K.passport_bn_bwd(dy, x, out[1], None, None, 0.0, None, None, None, None, True, True, dy2=dy2)
+    ref = K.passport_bn_bwd(dy + dy2, x, out[1], None, None, 0.0, None, None, None, None, True, True)
+    for u, v in zip(a, ref):
+        if u is not None:
+            assert torch.equal(u, v)
+    assert K.sync_timeouts() == 0
+
+
 # ----------------------------------------------------------------------------- SignLoss.set_b on the fused path
 def test_set_b_changes_the_fused_training_loss(K):
     from deepipr_amd.models.layers.passportconv2d import PassportBlock
