@@ -47,13 +47,21 @@ class ConvBlock(nn.Module):
         y = self(x, residual)                     # through __call__: module hooks see the layer (output: the pair)
         return y if isinstance(y, tuple) else P.add_relu_fork(y, residual)
 
-    def forward(self, x, _residual=None):
+    def forward_fork(self, x):
+        """-> two handles of self(x) for a layer whose output feeds two consumers (the CIFAR stem feeds layer1's first
+        conv and its identity shortcut): with the fused norm kernels their gradients are summed inside the backward
+        kernel."""
+        y = self(x, None, True)
+        return y if isinstance(y, tuple) else (y, y)
+
+    def forward(self, x, _residual=None, _fork=False):
         x = self.conv(x)
         if (self.fuse_norm and x.is_cuda and x.numel() >= FUSE_MIN_ELEMENTS and isinstance(self.bn, nn.BatchNorm2d)
                 and self.bn.affine and self.bn.momentum is not None and x.dtype == torch.float32):
             from deepipr_amd import passport_ops as P
             tail = _residual if (_residual is not None and P.bn_tail_fusable(self.bn, x)) else None
-            return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None, tail)
+            fork = bool(_fork) and tail is None and _residual is None
+            return P.bn_affine_relu(x, self.bn.weight, self.bn.bias, self.bn, self.relu is not None, tail, fork)
         if self.fuse_norm and isinstance(self.bn, (nn.GroupNorm, nn.InstanceNorm2d)) and x.is_cuda:
             from deepipr_amd import passport_ops as P
             if P.gn_is_fusable(self.bn, x):          # GroupNorm(affine) / InstanceNorm2d + ReLU in one kernel

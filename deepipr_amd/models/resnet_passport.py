@@ -96,9 +96,15 @@ class ResNetPassport(nn.Module):
         return nn.Sequential(*layers)
 
     def _stem(self, x, force_passport, ind):
+        """-> two handles (out, skip) of the stem's output: it feeds layer1's first conv AND its identity shortcut."""
+        from deepipr_amd.models.layers.conv2d import ConvBlock
         if isinstance(self.convbnrelu_1, nn.Sequential):
-            return self.convbnrelu_1[1](run_layer(self.convbnrelu_1[0], x, force_passport, ind))
-        return run_layer(self.convbnrelu_1, x, force_passport, ind)
+            y = self.convbnrelu_1[1](run_layer(self.convbnrelu_1[0], x, force_passport, ind))
+            return y, y
+        if isinstance(self.convbnrelu_1, ConvBlock):
+            return self.convbnrelu_1.forward_fork(x)
+        y = run_layer(self.convbnrelu_1, x, force_passport, ind)
+        return y, y
 
     def set_intermediate_keys(self, pretrained_model, x, y=None):
         """models/resnet_passport.py:145-161."""
@@ -114,7 +120,7 @@ class ResNetPassport(nn.Module):
                     x, y = mine.set_intermediate_keys(theirs, x, y)
 
     def forward(self, x, force_passport=False, ind=0):
-        out = skip = self._stem(x, force_passport, ind)
+        out, skip = self._stem(x, force_passport, ind)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for block in layer:
                 out, skip = block.forward_pair(out, skip, force_passport, ind)

@@ -712,11 +712,13 @@ def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, 
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
-def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None):
+def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False):
     """Fused public branch: BatchNorm2d(affine=False) + learnable gamma/beta + ReLU; with `residual` the pair of
-    handles of relu(that + residual)."""
+    handles of relu(that + residual).  fork=True hands the output out as a pair of handles as well (a layer whose
+    output has two consumers without being a block's tail -- the CIFAR stem): the consumers' gradients then reach the
+    backward kernel separately and are summed there instead of by an ATen add pass."""
     out = _bn_apply(x, None, None, None, gamma, beta, None, None, bn, 0.0, relu, 1, 0, residual)
-    return (out[0], out[1]) if residual is not None else out[0]
+    return (out[0], out[1]) if (residual is not None or fork) else out[0]
 
 
 def conv_out_shape(x, conv):
