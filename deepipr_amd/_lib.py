@@ -50,6 +50,8 @@ SIGNATURES = {
     'deepipr_relu_bwd2': (_int, [_f32p, _f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
+    'deepipr_sgd_momentum_chunk': (_int, []),
+    'deepipr_sgd_momentum_step_multi': (_int, [_f32p, _f32p, _vp, _int, _sz, _f32p, _vp]),
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),

@@ -2020,6 +2020,47 @@ __global__ __launch_bounds__(kThreads) void k_sgd_momentum_s(float *__restrict__
 }
 
 
+// The same update with the gradients read WHERE AUTOGRAD LEFT THEM: one workgroup per table entry
+// {gradient address, offset into the flat parameter / momentum buffers, element count <= kSgdChunk}.  No packing pass
+// (FlatSGD's `cat` of 44.7 MB of gradients into the flat gradient buffer: 26 us and 89 MB per step) is needed when
+// the gradients need not be contiguous, i.e. without a gradient all-reduce; the addresses are stable when the step
+// is replayed from a hipGraph, so the table is built once at capture time.
+constexpr int kSgdChunk = 4096;
+
+__global__ __launch_bounds__(kThreads) void k_sgd_momentum_multi(float *__restrict__ p, float *__restrict__ buf,
+                                                                 const long long *__restrict__ table,
+                                                                 const float *__restrict__ hp) {
+    const long long *e = table + 3 * static_cast<size_t>(blockIdx.x);
+    const float *__restrict__ g = reinterpret_cast<const float *>(static_cast<uintptr_t>(e[0]));
+    const size_t off = static_cast<size_t>(e[1]);
+    const int n = static_cast<int>(e[2]);
+    const float lr = hp[0], mu = hp[1], wd = hp[2], gs = hp[3];
+    float *pp = p + off, *bb = buf + off;
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (off & 3u) == 0) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        float4 *p4 = reinterpret_cast<float4 *>(pp), *b4 = reinterpret_cast<float4 *>(bb);
+        for (int i = threadIdx.x; i < n / 4; i += kThreads) {
+            float4 pv = p4[i], bv = b4[i];
+            const float4 gv = g4[i];
+            float d;
+            d = fmaf(wd, pv.x, gs * gv.x); bv.x = fmaf(mu, bv.x, d); pv.x = fmaf(-lr, bv.x, pv.x);
+            d = fmaf(wd, pv.y, gs * gv.y); bv.y = fmaf(mu, bv.y, d); pv.y = fmaf(-lr, bv.y, pv.y);
+            d = fmaf(wd, pv.z, gs * gv.z); bv.z = fmaf(mu, bv.z, d); pv.z = fmaf(-lr, bv.z, pv.z);
+            d = fmaf(wd, pv.w, gs * gv.w); bv.w = fmaf(mu, bv.w, d); pv.w = fmaf(-lr, bv.w, pv.w);
+            p4[i] = pv;
+            b4[i] = bv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+            const float d = fmaf(wd, pp[i], gs * g[i]);
+            const float b = fmaf(mu, bb[i], d);
+            bb[i] = b;
+            pp[i] = fmaf(-lr, b, pp[i]);
+        }
+    }
+}
+
+
 // ============================================================================================
 // Residual tail of a block: out = relu(a + b)  (models/resnet_passport.py:77-84: out += shortcut; F.relu(out)).
 // One 12 B/elt pass instead of ATen's add (12 B/elt) + relu (8 B/elt); backward is one masked copy shared by
@@ -3004,6 +3045,19 @@ int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_b
     if (!param || !grad || !momentum_buf || n == 0) return fail(DEEPIPR_EINVAL, "sgd_momentum_step: bad argument");
     return launch_sgd(param, grad, momentum_buf, n, lr, momentum, weight_decay, grad_scale, nullptr,
                       static_cast<hipStream_t>(stream));
+}
+
+int deepipr_sgd_momentum_chunk(void) { return kSgdChunk; }
+
+int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const long long *table, int entries,
+                                    size_t total_elements, const float *hyper, void *stream) {
+    if (!param || !momentum_buf || !table || !hyper || entries <= 0)
+        return fail(DEEPIPR_EINVAL, "sgd_momentum_step_multi: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_SGD, st);
+    prof.bytes = 20.0 * static_cast<double>(total_elements);
+    DEEPIPR_LAUNCH(prof, k_sgd_momentum_multi, dim3(entries), dim3(kThreads), st, param, momentum_buf, table, hyper);
+    return check_launch("sgd_momentum_step_multi");
 }
 
 int deepipr_sgd_momentum_step_dev(float *param, const float *grad, float *momentum_buf, size_t n,

@@ -445,6 +445,20 @@ class HipKernels:
                                                            flat_param.numel(), lr, momentum, weight_decay,
                                                            grad_scale, _stream(dev)), 'sgd_momentum_step')
 
+    def sgd_chunk(self):
+        return _lib.lib().deepipr_sgd_momentum_chunk()
+
+    def sgd_momentum_step_multi(self, flat_param, flat_buf, table, total_elements, hyper):
+        """SGD with the gradients read in place: `table` is an int64 device tensor [entries, 3] of
+        {gradient chunk address, offset into the flat buffers, count} (include/deepipr_hip.h)."""
+        dev = _chk(flat_param, flat_buf, hyper)
+        if table.dtype != torch.int64 or not table.is_cuda or not table.is_contiguous():
+            raise RuntimeError('sgd_momentum_step_multi: table must be a contiguous int64 device tensor')
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_sgd_momentum_step_multi(_p(flat_param), _p(flat_buf), table.data_ptr(),
+                                                                 table.shape[0], int(total_elements), _p(hyper),
+                                                                 _stream(dev)), 'sgd_momentum_step_multi')
+
     def sgd_momentum_step_dev(self, flat_param, flat_grad, flat_buf, hyper):
         """The same with {lr, momentum, weight_decay, grad_scale} read from the 4-float DEVICE tensor `hyper`, so a
         step captured in a hipGraph follows a learning-rate schedule."""

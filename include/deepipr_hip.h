@@ -283,6 +283,15 @@ int deepipr_sgd_momentum_step(float *param, const float *grad, float *momentum_b
  * the host rewrites the floats between replays. */
 int deepipr_sgd_momentum_step_dev(float *param, const float *grad, float *momentum_buf, size_t n,
                                   const float *hyper, void *stream);
+/* The same update with the gradients read where autograd left them -- no packing pass into a flat gradient buffer.
+ * `table` (device): `entries` rows of three 64-bit integers {address of a gradient chunk, offset (in floats) of the
+ * matching chunk in param / momentum_buf, element count <= deepipr_sgd_momentum_chunk()}; one workgroup per row.
+ * Meant for a step captured into a hipGraph on one GPU (the gradient addresses are then stable and the table is built
+ * once); with a gradient all-reduce the gradients have to be contiguous anyway and deepipr_sgd_momentum_step_dev is
+ * used.  total_elements is only used for the byte accounting of deepipr_profile_read_bytes. */
+int deepipr_sgd_momentum_chunk(void);
+int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const long long *table, int entries,
+                                    size_t total_elements, const float *hyper, void *stream);
 
 /* ------------------------------------------------------------------ residual tail of a block
  * out = relu(a + b) in one pass (12 B/element), and its backward d = dy * [out > 0] (the same gradient goes

@@ -518,3 +518,34 @@ def test_graph_replay_follows_the_lr_schedule(K, flat):
             assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
     # and the schedule really acted: a frozen lr of 0.05 would have moved the weights ~3.4x further in epochs 2-3
     assert K.sync_timeouts() == 0
+
+
+@pytest.mark.miopen_pinned
+def test_captured_flat_sgd_reads_gradients_in_place(K):
+    """One GPU, step captured into a hipGraph: FlatSGD updates from the gradient tensors where autograd left them
+    (deepipr_sgd_momentum_step_multi, chunk table built at capture time) instead of packing them into flat_grad first.
+    Same trajectory as the eager FlatSGD step (which packs), over steps with changing inputs."""
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.flat_sgd import FlatSGD
+    from tests.test_parity_gpu import _fullsize_pair
+    finals = []
+    for graphed in (False, True):
+        prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+        x, y = x.to(DEV), y.to(DEV)
+        opt = FlatSGD(prod.parameters(), **SGD)
+        with pinned_miopen():
+            if graphed:
+                g = GraphedTrainStep(train_step_v1, prod, opt, x, y, warmup=0)
+                assert opt.in_place_captures == 1
+                for i in range(4):
+                    g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+            else:
+                for i in range(4):
+                    train_step_v1(prod, opt, x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+                assert opt.in_place_captures == 0
+            torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in prod.state_dict().items()})
+    for k in finals[0]:
+        if finals[0][k].dtype.is_floating_point:
+            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
