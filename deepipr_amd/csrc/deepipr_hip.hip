@@ -2062,6 +2062,84 @@ __global__ __launch_bounds__(kThreads) void k_sgd_momentum_multi(float *__restri
 
 
 // ============================================================================================
+// Head of the train step: mean cross-entropy + top-1 accuracy of logits [N][C] in ONE launch, and its backward in one
+// (experiments/trainer.py:136,149: F.cross_entropy(pred, target) and accuracy(pred, target)[0] -- log_softmax,
+// nll_loss, topk, eq, sum, mul_ and their backward: ~12 launch-latency-bound ATen kernels per step).
+// One workgroup; a wavefront per row (lanes stride over the classes), f64 accumulation, fixed-order combine.
+// ============================================================================================
+constexpr int kCeThreads = 1024;
+
+__global__ __launch_bounds__(kCeThreads) void k_ce_top1_fwd(const float *__restrict__ logits,
+                                                            const long long *__restrict__ target, int N, int C,
+                                                            float *__restrict__ loss, float *__restrict__ top1_pct,
+                                                            float *__restrict__ lse) {
+    constexpr int NW = kCeThreads / kWave;
+    __shared__ double red[2 * NW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double loss_acc = 0.0, hit_acc = 0.0;
+    for (int n = wave; n < N; n += NW) {
+        const float *row = logits + static_cast<size_t>(n) * C;
+        float mx = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int c = lane; c < C; c += kWave) {
+            const float v = row[c];
+            if (v > mx || (v == mx && c < arg)) {
+                mx = v;
+                arg = c;
+            }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {           // arg-max butterfly: larger value, then lower index
+            const float ov = __shfl_xor(mx, off, kWave);
+            const int oa = __shfl_xor(arg, off, kWave);
+            if (ov > mx || (ov == mx && oa < arg)) {
+                mx = ov;
+                arg = oa;
+            }
+        }
+        double sum = 0.0;
+        for (int c = lane; c < C; c += kWave) sum += exp(static_cast<double>(row[c]) - static_cast<double>(mx));
+        sum = wave_sum(sum);
+        const double l = static_cast<double>(mx) + log(sum);
+        const long long t = target[n];
+        if (lane == 0) {
+            lse[n] = static_cast<float>(l);
+            loss_acc += l - static_cast<double>(row[t]);
+            hit_acc += (static_cast<long long>(arg) == t) ? 1.0 : 0.0;
+        }
+    }
+    if (lane == 0) {
+        red[wave] = loss_acc;
+        red[NW + wave] = hit_acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < NW; ++w) {
+            a += red[w];
+            b += red[NW + w];
+        }
+        *loss = static_cast<float>(a / N);
+        *top1_pct = static_cast<float>(b * (100.0 / N));
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_ce_bwd(const float *__restrict__ dloss, const float *__restrict__ logits,
+                                                     const long long *__restrict__ target,
+                                                     const float *__restrict__ lse, int N, int C,
+                                                     float *__restrict__ dlogits) {
+    const float scale = dloss[0] / static_cast<float>(N);
+    const size_t total = static_cast<size_t>(N) * C;
+    const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += step) {
+        const int n = static_cast<int>(i / C), c = static_cast<int>(i - static_cast<size_t>(n) * C);
+        const float p = expf(logits[i] - lse[n]);
+        dlogits[i] = scale * (p - (static_cast<long long>(c) == target[n] ? 1.0f : 0.0f));
+    }
+}
+
+
+// ============================================================================================
 // Residual tail of a block: out = relu(a + b)  (models/resnet_passport.py:77-84: out += shortcut; F.relu(out)).
 // One 12 B/elt pass instead of ATen's add (12 B/elt) + relu (8 B/elt); backward is one masked copy shared by
 // both inputs: d = dy * [out > 0].
@@ -3067,6 +3145,31 @@ int deepipr_sgd_momentum_step_dev(float *param, const float *grad, float *moment
     return launch_sgd(param, grad, momentum_buf, n, 0.0f, 0.0f, 0.0f, 1.0f, hyper, static_cast<hipStream_t>(stream));
 }
 
+
+int deepipr_ce_top1_supported(int N, int C) {
+    return (N > 0 && C > 0 && static_cast<long long>(N) * C <= (1ll << 20)) ? 1 : 0;
+}
+
+int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int C, float *loss, float *top1_pct,
+                        float *lse, void *stream) {
+    if (!logits || !target || !loss || !top1_pct || !lse || N <= 0 || C <= 0)
+        return fail(DEEPIPR_EINVAL, "ce_top1_fwd: bad argument");
+    if (!deepipr_ce_top1_supported(N, C))
+        return fail(DEEPIPR_EUNSUPPORTED, "ce_top1_fwd: more than 2^20 logits (use the library ops)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_ce_top1_fwd, dim3(1), dim3(kCeThreads), 0, st, logits, target, N, C, loss, top1_pct, lse);
+    return check_launch("ce_top1_fwd");
+}
+
+int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,
+                   float *dlogits, void *stream) {
+    if (!dloss || !logits || !target || !lse || !dlogits || N <= 0 || C <= 0)
+        return fail(DEEPIPR_EINVAL, "ce_bwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(static_cast<size_t>(N) * C)), dim3(kThreads), 0, st, dloss, logits,
+                       target, lse, N, C, dlogits);
+    return check_launch("ce_bwd");
+}
 
 int deepipr_add_relu_fwd(const float *a, const float *b, float *out, size_t n, void *stream) {
     if (!a || !b || !out || n == 0) return fail(DEEPIPR_EINVAL, "add_relu_fwd: bad argument");

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from deepipr_amd.models.losses.sign_loss import SignLoss
+from deepipr_amd.passport_ops import cross_entropy_top1
 
 
 def accuracy(output, target, topk=(1,)):
@@ -74,11 +75,11 @@ def train_step_v1(model, optimizer, data, target):
     optimizer.zero_grad(set_to_none=True)
     reset_sign_losses(model)
     pred = model(data)
-    loss = F.cross_entropy(pred, target)
+    loss, top1 = cross_entropy_top1(pred, target)          # F.cross_entropy + accuracy()[0], one fused launch on the GPU
     sign_loss = total_sign_loss(model, data.device)
     (loss + sign_loss).backward()
     optimizer.step()
-    return loss.detach(), sign_loss.detach(), accuracy(pred, target)[0][0]
+    return loss.detach(), sign_loss.detach(), top1
 
 
 class Tester(object):

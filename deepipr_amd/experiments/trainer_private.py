@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from deepipr_amd.experiments.trainer import (StepRunner, _check_exchange, accuracy, mean_sign_acc, next_trigger_batch,
+from deepipr_amd.experiments.trainer import (StepRunner, _check_exchange, accuracy, cross_entropy_top1, mean_sign_acc,
+                                             next_trigger_batch,
                                              reset_sign_losses, total_sign_loss)
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
@@ -40,12 +41,13 @@ def train_step_v23(dual, optimizer, data, target):
     optimizer.zero_grad(set_to_none=True)
     reset_sign_losses(dual)
     pred_public, pred_private = dual(data)
-    loss = F.cross_entropy(pred_public, target) + F.cross_entropy(pred_private, target)
+    loss_public, top1_public = cross_entropy_top1(pred_public, target)
+    loss_private, top1_private = cross_entropy_top1(pred_private, target)
+    loss = loss_public + loss_private
     sign_loss = total_sign_loss(dual, data.device)
     (loss + sign_loss).backward()
     optimizer.step()
-    return (loss.detach(), sign_loss.detach(), accuracy(pred_public, target)[0][0],
-            accuracy(pred_private, target)[0][0])
+    return loss.detach(), sign_loss.detach(), top1_public, top1_private
 
 
 class TesterPrivate(object):

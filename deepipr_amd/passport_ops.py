@@ -445,6 +445,32 @@ class HipKernels:
                                                            flat_param.numel(), lr, momentum, weight_decay,
                                                            grad_scale, _stream(dev)), 'sgd_momentum_step')
 
+    # ---- head of the train step: cross-entropy + top-1 in one launch (include/deepipr_hip.h: deepipr_ce_*) ----
+    def ce_usable(self, logits, target):
+        return (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and target.dim() == 1
+                and target.dtype == torch.int64 and target.device == logits.device
+                and bool(_lib.lib().deepipr_ce_top1_supported(logits.shape[0], logits.shape[1])))
+
+    def ce_top1_fwd(self, logits, target):
+        """-> loss (mean CE), top-1 accuracy in percent, lse[N]."""
+        dev = _chk(logits)
+        n, c = logits.shape
+        out = torch.empty(2 + n, dtype=torch.float32, device=dev)
+        base = out.data_ptr()
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_ce_top1_fwd(logits.data_ptr(), target.data_ptr(), n, c, base, base + 4,
+                                                     base + 8, _stream(dev)), 'ce_top1_fwd')
+        return out[0], out[1], out[2:]
+
+    def ce_bwd(self, dloss, logits, target, lse):
+        dev = _chk(dloss, logits, lse)
+        n, c = logits.shape
+        dlogits = torch.empty_like(logits)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_ce_bwd(dloss.data_ptr(), logits.data_ptr(), target.data_ptr(),
+                                                lse.data_ptr(), n, c, dlogits.data_ptr(), _stream(dev)), 'ce_bwd')
+        return dlogits
+
     def sgd_chunk(self):
         return _lib.lib().deepipr_sgd_momentum_chunk()
 
@@ -845,6 +871,38 @@ def gn_affine_relu(x, gamma, beta, norm, relu=True):
     """Fused W-less branch: GroupNorm / InstanceNorm2d + per-channel gamma/beta (None = 1 / 0) + ReLU."""
     cfg = (0.0, bool(relu), 1, 0, norm_groups(norm), norm.eps)
     return _PassportGNLayer.apply(x, None, None, None, gamma, beta, None, None, cfg)[0]
+
+
+class _CrossEntropyTop1(torch.autograd.Function):
+    """Mean cross-entropy and top-1 accuracy (percent) of logits [N, C] in one launch, backward in one."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = logits.contiguous(), target.contiguous()
+        loss, top1, lse = kernels.ce_top1_fwd(logits, target)
+        ctx.save_for_backward(logits, target, lse)
+        ctx.mark_non_differentiable(top1)
+        ctx.set_materialize_grads(False)
+        return loss, top1
+
+    @staticmethod
+    def backward(ctx, dloss, _dtop1):
+        if dloss is None:
+            return None, None
+        logits, target, lse = ctx.saved_tensors
+        return kernels.ce_bwd(dloss.contiguous(), logits, target, lse), None
+
+
+def cross_entropy_top1(pred, target):
+    """-> (F.cross_entropy(pred, target), top-1 accuracy in percent) -- experiments/trainer.py:136,149.  On the GPU
+    both come from one fused launch (and one for the backward); anything the kernel does not take (other dtypes,
+    more than 2^20 logits) goes through the library ops."""
+    if kernels.ce_usable(pred, target):
+        return _CrossEntropyTop1.apply(pred, target)
+    loss = torch.nn.functional.cross_entropy(pred, target)
+    with torch.no_grad():
+        top1 = pred.argmax(dim=1).eq(target).float().sum() * (100.0 / target.size(0))
+    return loss, top1
 
 
 class _AddReLU(torch.autograd.Function):

@@ -293,6 +293,21 @@ int deepipr_sgd_momentum_chunk(void);
 int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const long long *table, int entries,
                                     size_t total_elements, const float *hyper, void *stream);
 
+/* ------------------------------------------------------------------ head of the train step
+ * loss = mean_n( logsumexp(logits[n]) - logits[n][target[n]] ),  top1_pct = 100 * mean_n( argmax(logits[n]) ==
+ * target[n] ) (ties: the lowest class index), lse[n] = logsumexp(logits[n]) saved for backward; one launch.
+ * dlogits[n][c] = dloss/N * (exp(logits[n][c] - lse[n]) - [c == target[n]]); `dloss` is a device scalar.
+ * replaces: F.cross_entropy(pred, target) and accuracy(pred, target)[0] of experiments/trainer.py:136,149
+ *           (trainer_private.py:161-166) -- log_softmax, nll_loss, topk, eq, sum, mul_ and their backward.
+ * target: int64 class indices in [0, C) (the caller guarantees the range; no ignore_index).  Up to 2^20 logits
+ * (deepipr_ce_top1_supported): larger problems return DEEPIPR_EUNSUPPORTED without enqueuing anything.
+ * logits, dlogits [N][C] f32; loss, top1_pct: one float each; lse [N]. */
+int deepipr_ce_top1_supported(int N, int C);
+int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int C, float *loss, float *top1_pct,
+                        float *lse, void *stream);
+int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,
+                   float *dlogits, void *stream);
+
 /* ------------------------------------------------------------------ residual tail of a block
  * out = relu(a + b) in one pass (12 B/element), and its backward d = dy * [out > 0] (the same gradient goes
  * to both inputs).  All pointers 16-byte aligned, n floats.

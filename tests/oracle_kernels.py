@@ -227,3 +227,20 @@ class OracleKernels:
 
     def prepare_stream(self, dev, stream=None):
         return None
+
+    # ---- head of the train step (deepipr_ce_*): float64 restatement of F.cross_entropy + top-1
+    def ce_usable(self, logits, target):
+        return logits.dtype == torch.float32 and logits.dim() == 2 and target.dtype == torch.int64
+
+    def ce_top1_fwd(self, logits, target):
+        x = logits.detach().double()
+        lse = torch.logsumexp(x, dim=1)
+        loss = (lse - x.gather(1, target.view(-1, 1)).view(-1)).mean()
+        top1 = x.argmax(dim=1).eq(target).double().mean() * 100.0
+        return loss.float(), top1.float(), lse.float()
+
+    def ce_bwd(self, dloss, logits, target, lse):
+        x = logits.detach().double()
+        p = torch.exp(x - lse.double().view(-1, 1))
+        p[torch.arange(x.shape[0]), target] -= 1.0
+        return (p * (dloss.double() / x.shape[0])).float()

@@ -549,3 +549,29 @@ def test_captured_flat_sgd_reads_gradients_in_place(K):
     for k in finals[0]:
         if finals[0][k].dtype.is_floating_point:
             assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+
+
+@pytest.mark.parametrize('n,c', [(128, 10), (66, 100), (32, 100), (8, 1000), (256, 1000), (1, 2), (7, 1)])
+def test_fused_cross_entropy_and_top1(K, n, c):
+    """deepipr_ce_top1_fwd / deepipr_ce_bwd against F.cross_entropy + the reference's accuracy() (trainer.py:28-43,
+    136) in float64: loss 1e-6, gradient 1e-6 of its scale, top-1 identical (ties: lowest index, as argmax)."""
+    from deepipr_amd import passport_ops as P
+    rs = np.random.RandomState(n + c)
+    logits = (rs.standard_normal((n, c)) * 3).astype(np.float32)
+    if c >= 2:
+        logits[0, 1] = logits[0, 0] = logits[0].max() + 1.0             # a tie for the maximum: class 0 wins
+    target = rs.randint(0, c, size=n).astype(np.int64)
+    x = dev(logits).requires_grad_(True)
+    t = torch.from_numpy(target).to(DEV)
+    assert P.kernels.ce_usable(x, t)
+    loss, top1 = P.cross_entropy_top1(x, t)
+    (loss * 1.7).backward()
+    xr = torch.from_numpy(logits).double().requires_grad_(True)
+    lr = torch.nn.functional.cross_entropy(xr, torch.from_numpy(target))
+    (lr * 1.7).backward()
+    assert abs(float(loss) - float(lr)) <= 1e-6 * max(1.0, abs(float(lr)))
+    want_top1 = float((torch.from_numpy(logits).argmax(dim=1) == torch.from_numpy(target)).double().mean() * 100.0)
+    assert float(top1) == pytest.approx(want_top1, abs=1e-4)
+    g_ref = xr.grad.numpy()
+    assert np.abs(host(x.grad) - g_ref).max() <= 1e-6 * max(1e-3, np.abs(g_ref).max())
+    assert not top1.requires_grad
