@@ -2098,7 +2098,7 @@ __global__ __launch_bounds__(kCeThreads) void k_ce_top1_fwd(const float *__restr
             }
         }
         double sum = 0.0;
-        for (int c = lane; c < C; c += kWave) sum += exp(static_cast<double>(row[c]) - static_cast<double>(mx));
+        for (int c = lane; c < C; c += kWave) sum += static_cast<double>(expf(row[c] - mx));     // terms <= 1, f64 sum
         sum = wave_sum(sum);
         const double l = static_cast<double>(mx) + log(sum);
         const long long t = target[n];
