@@ -46,7 +46,8 @@ SIGNATURES = {
     'deepipr_passport_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f64p, _f32p, _flt, _flt, _flt, _f32p, _f32p,
                                     _f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _vp, _vp]),
     'deepipr_ce_top1_supported': (_int, [_int, _int]),
-    'deepipr_ce_top1_fwd': (_int, [_f32p, _vp, _int, _int, _f32p, _f32p, _f32p, _vp]),
+    'deepipr_ce_top1_workspace_bytes': (_sz, [_int]),
+    'deepipr_ce_top1_fwd': (_int, [_f32p, _vp, _int, _int, _f32p, _f32p, _f32p, _vp, _vp]),
     'deepipr_ce_bwd': (_int, [_f32p, _f32p, _vp, _f32p, _int, _int, _f32p, _vp]),
     'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),

@@ -2067,58 +2067,58 @@ __global__ __launch_bounds__(kThreads) void k_sgd_momentum_multi(float *__restri
 // nll_loss, topk, eq, sum, mul_ and their backward: ~12 launch-latency-bound ATen kernels per step).
 // One workgroup; a wavefront per row (lanes stride over the classes), f64 accumulation, fixed-order combine.
 // ============================================================================================
-constexpr int kCeThreads = 1024;
-
-__global__ __launch_bounds__(kCeThreads) void k_ce_top1_fwd(const float *__restrict__ logits,
-                                                            const long long *__restrict__ target, int N, int C,
-                                                            float *__restrict__ loss, float *__restrict__ top1_pct,
-                                                            float *__restrict__ lse) {
-    constexpr int NW = kCeThreads / kWave;
-    __shared__ double red[2 * NW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double loss_acc = 0.0, hit_acc = 0.0;
-    for (int n = wave; n < N; n += NW) {
-        const float *row = logits + static_cast<size_t>(n) * C;
-        float mx = -INFINITY;
-        int arg = 0x7fffffff;
-        for (int c = lane; c < C; c += kWave) {
-            const float v = row[c];
-            if (v > mx || (v == mx && c < arg)) {
-                mx = v;
-                arg = c;
-            }
+// Forward = two launches: k_ce_rows (one wavefront per row, all rows in parallel: per-row logsumexp, loss term and
+// arg-max hit) and k_ce_finish (one workgroup: fixed-order f64 sum over the rows -> mean loss, top-1 percent).
+// A first version looped one workgroup's 16 wavefronts over all rows: 20 us for 128 x 10 logits, a chain of dependent
+// load latencies per row; with a wavefront per row the pair takes ~2 x 3 us.
+__global__ __launch_bounds__(kThreads) void k_ce_rows(const float *__restrict__ logits,
+                                                      const long long *__restrict__ target, int N, int C,
+                                                      float *__restrict__ lse, double *__restrict__ part /* [N][2] */) {
+    const int n = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;                                           // whole wavefront
+    const float *row = logits + static_cast<size_t>(n) * C;
+    const long long t = target[n];
+    float mx = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < C; c += kWave) {
+        const float v = row[c];
+        if (v > mx || (v == mx && c < arg)) {
+            mx = v;
+            arg = c;
         }
+    }
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {           // arg-max butterfly: larger value, then lower index
-            const float ov = __shfl_xor(mx, off, kWave);
-            const int oa = __shfl_xor(arg, off, kWave);
-            if (ov > mx || (ov == mx && oa < arg)) {
-                mx = ov;
-                arg = oa;
-            }
-        }
-        double sum = 0.0;
-        for (int c = lane; c < C; c += kWave) sum += static_cast<double>(expf(row[c] - mx));     // terms <= 1, f64 sum
-        sum = wave_sum(sum);
-        const double l = static_cast<double>(mx) + log(sum);
-        const long long t = target[n];
-        if (lane == 0) {
-            lse[n] = static_cast<float>(l);
-            loss_acc += l - static_cast<double>(row[t]);
-            hit_acc += (static_cast<long long>(arg) == t) ? 1.0 : 0.0;
+    for (int off = kWave / 2; off > 0; off >>= 1) {               // arg-max butterfly: larger value, then lower index
+        const float ov = __shfl_xor(mx, off, kWave);
+        const int oa = __shfl_xor(arg, off, kWave);
+        if (ov > mx || (ov == mx && oa < arg)) {
+            mx = ov;
+            arg = oa;
         }
     }
+    double sum = 0.0;
+    for (int c = lane; c < C; c += kWave) sum += static_cast<double>(expf(row[c] - mx));     // terms <= 1, f64 sum
+    sum = wave_sum(sum);
     if (lane == 0) {
-        red[wave] = loss_acc;
-        red[NW + wave] = hit_acc;
+        const double l = static_cast<double>(mx) + log(sum);
+        lse[n] = static_cast<float>(l);
+        part[2 * static_cast<size_t>(n) + 0] = l - static_cast<double>(row[t]);
+        part[2 * static_cast<size_t>(n) + 1] = (static_cast<long long>(arg) == t) ? 1.0 : 0.0;
     }
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void k_ce_finish(const double *__restrict__ part, int N,
+                                                        float *__restrict__ loss, float *__restrict__ top1_pct) {
+    __shared__ double red[8];
+    double a = 0.0, b = 0.0;
+    for (int n = threadIdx.x; n < N; n += kThreads) {
+        a += part[2 * static_cast<size_t>(n) + 0];
+        b += part[2 * static_cast<size_t>(n) + 1];
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red + 4);
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < NW; ++w) {
-            a += red[w];
-            b += red[NW + w];
-        }
         *loss = static_cast<float>(a / N);
         *top1_pct = static_cast<float>(b * (100.0 / N));
     }
@@ -3150,14 +3150,20 @@ int deepipr_ce_top1_supported(int N, int C) {
     return (N > 0 && C > 0 && static_cast<long long>(N) * C <= (1ll << 20)) ? 1 : 0;
 }
 
+size_t deepipr_ce_top1_workspace_bytes(int N) { return N > 0 ? static_cast<size_t>(N) * 2 * sizeof(double) : 0; }
+
 int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int C, float *loss, float *top1_pct,
-                        float *lse, void *stream) {
-    if (!logits || !target || !loss || !top1_pct || !lse || N <= 0 || C <= 0)
+                        float *lse, void *workspace, void *stream) {
+    if (!logits || !target || !loss || !top1_pct || !lse || !workspace || N <= 0 || C <= 0)
         return fail(DEEPIPR_EINVAL, "ce_top1_fwd: bad argument");
     if (!deepipr_ce_top1_supported(N, C))
         return fail(DEEPIPR_EUNSUPPORTED, "ce_top1_fwd: more than 2^20 logits (use the library ops)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_ce_top1_fwd, dim3(1), dim3(kCeThreads), 0, st, logits, target, N, C, loss, top1_pct, lse);
+    double *part = static_cast<double *>(workspace);
+    const int rows_per_wg = kThreads / kWave;
+    hipLaunchKernelGGL(k_ce_rows, dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(kThreads), 0, st, logits, target, N, C,
+                       lse, part);
+    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(kThreads), 0, st, part, N, loss, top1_pct);
     return check_launch("ce_top1_fwd");
 }
 

@@ -457,9 +457,11 @@ class HipKernels:
         n, c = logits.shape
         out = torch.empty(2 + n, dtype=torch.float32, device=dev)
         base = out.data_ptr()
+        st = _stream(dev)
+        ws = self._scratch(dev, st, 16 * n)                 # per-row loss terms and hits, f64 (written and consumed here)
         with _on(dev):
             _lib.check(_lib.lib().deepipr_ce_top1_fwd(logits.data_ptr(), target.data_ptr(), n, c, base, base + 4,
-                                                     base + 8, _stream(dev)), 'ce_top1_fwd')
+                                                     base + 8, ws, st), 'ce_top1_fwd')
         return out[0], out[1], out[2:]
 
     def ce_bwd(self, dloss, logits, target, lse):

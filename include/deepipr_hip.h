@@ -295,7 +295,8 @@ int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const lon
 
 /* ------------------------------------------------------------------ head of the train step
  * loss = mean_n( logsumexp(logits[n]) - logits[n][target[n]] ),  top1_pct = 100 * mean_n( argmax(logits[n]) ==
- * target[n] ) (ties: the lowest class index), lse[n] = logsumexp(logits[n]) saved for backward; one launch.
+ * target[n] ) (ties: the lowest class index), lse[n] = logsumexp(logits[n]) saved for backward; two launches (a
+ * wavefront per row, then a fixed-order sum over the rows).  workspace: deepipr_ce_top1_workspace_bytes(N) bytes.
  * dlogits[n][c] = dloss/N * (exp(logits[n][c] - lse[n]) - [c == target[n]]); `dloss` is a device scalar.
  * replaces: F.cross_entropy(pred, target) and accuracy(pred, target)[0] of experiments/trainer.py:136,149
  *           (trainer_private.py:161-166) -- log_softmax, nll_loss, topk, eq, sum, mul_ and their backward.
@@ -303,8 +304,9 @@ int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const lon
  * (deepipr_ce_top1_supported): larger problems return DEEPIPR_EUNSUPPORTED without enqueuing anything.
  * logits, dlogits [N][C] f32; loss, top1_pct: one float each; lse [N]. */
 int deepipr_ce_top1_supported(int N, int C);
+size_t deepipr_ce_top1_workspace_bytes(int N);
 int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int C, float *loss, float *top1_pct,
-                        float *lse, void *stream);
+                        float *lse, void *workspace, void *stream);
 int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,
                    float *dlogits, void *stream);
 

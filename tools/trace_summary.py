@@ -3,7 +3,7 @@
 
 MIOpen's find mode (cudnn.benchmark) and the warm-up pollute whole-process statistics, so the window is
 cut by a once-per-step kernel: it spans the last `--steps` occurrences of the cross-entropy forward
-kernel (k_ce_top1_fwd; nll_loss_forward* for the library head), i.e. exactly that many full train steps.
+kernel (k_ce_finish; nll_loss_forward* for the library head), i.e. exactly that many full train steps.
 
     python tools/trace_summary.py <kernel_trace.csv> --steps 20 [--top 25] > profiles/<name>.md
 """
@@ -17,14 +17,14 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--top', type=int, default=25)
-    ap.add_argument('--marker', default=None, help='once-per-step kernel (default: k_ce_top1_fwd, else nll_loss_forward)')
+    ap.add_argument('--marker', default=None, help='once-per-step kernel (default: k_ce_finish, else nll_loss_forward)')
     args = ap.parse_args()
     rows = []
     with open(args.csv) as f:
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    for marker in ([args.marker] if args.marker else ['k_ce_top1_fwd', 'nll_loss_forward']):
+    for marker in ([args.marker] if args.marker else ['k_ce_finish', 'nll_loss_forward']):
         marks = [i for i, r in enumerate(rows) if marker in r[2]]
         if len(marks) > args.steps:
             break
