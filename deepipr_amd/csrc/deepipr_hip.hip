@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kThreads) void k_passport_bwd_finish(
             dbeta[co] = db;
         }
     }
-    write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);
+    if (dW) write_dw_rows<VEC, RPW>(dW, s, C, K, co0, dgv, dbv);      // dW == nullptr: the caller accumulates it later
 }
 
 
@@ -2284,7 +2284,7 @@ int launch_passport_finish(const double *part, int NS, int C, const float *gamma
                            const float *dbeta_extra, const double *s, int K, float *dgamma, float *dbeta, float *dW,
                            hipStream_t st) {
     ProfScope prof(DEEPIPR_K_PASSPORT_BWD_FINISH, st);
-    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
+    const bool vec = dW && K % 4 == 0 && aligned16(dW) && aligned16(s);
 #define DEEPIPR_FINISH_ARGS part, NS, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, s, K, dgamma, dbeta, dW
     if (C >= 2 * kRowPairMinCo) {
         const dim3 grid((C + 1) / 2);
@@ -2521,9 +2521,9 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
                          const float *dloss, const float *dgamma_extra, const float *dbeta_extra, int N, int C,
                          int HW, int K, int relu,
                          float *dxhat, float *dW, float *dgamma, float *dbeta, void *workspace, void *stream) {
-    if (!dy || !xhat || !gamma || !beta || !s || !dxhat || !dW || !dgamma || !dbeta || !workspace ||
-        bad_dims(N, C, HW) || K <= 0)
+    if (!dy || !xhat || !gamma || !beta || !dxhat || !dgamma || !dbeta || !workspace || bad_dims(N, C, HW))
         return fail(DEEPIPR_EINVAL, "passport_bwd: bad argument");
+    if (dW && (!s || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_bwd: dW needs m and K");
     if (dloss && !b) return fail(DEEPIPR_EINVAL, "passport_bwd: sign loss needs b");
     hipStream_t st = static_cast<hipStream_t>(stream);
     BwdPlan pl;
@@ -3058,6 +3058,7 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
         return fail(DEEPIPR_EINVAL, "passport_gn_bwd: bad argument");
     if (dW && (!m || !gamma || K <= 0)) return fail(DEEPIPR_EINVAL, "passport_gn_bwd: dW needs m, gamma and K");
     if (dloss && (!b || !gamma)) return fail(DEEPIPR_EINVAL, "passport_gn_bwd: sign loss needs b and gamma");
+    if (!dW && (dgamma_extra || dbeta_extra) && !gamma) return fail(DEEPIPR_EINVAL, "passport_gn_bwd: gamma missing");
     GnPlan pl;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !plan_gn(N, C, HW, groups, &pl))
         return fail(DEEPIPR_EUNSUPPORTED, "passport_gn_bwd: group does not fit the fused form");
@@ -3085,12 +3086,14 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
         int rc = check_launch("passport_gn_bwd");
         if (rc != DEEPIPR_OK) return rc;
     }
-    if (!dW) {
+    if (!dW && !dloss && !dgamma_extra && !dbeta_extra) {
         ProfScope prof(DEEPIPR_K_REDUCE_PARTIALS, st);
         DEEPIPR_LAUNCH(prof, k_reduce_partials, dim3((C + 3) / 4), dim3(kThreads), st, part, N, C,
                        dgamma, dbeta);
         return check_launch("passport_gn_bwd(finish)");
     }
+    // (dW == nullptr with a sign loss / external dgamma, dbeta: the passport branch whose rank-2 update the caller adds
+    // to the data convolution's wgrad afterwards, deepipr_gamma_beta_bwd_acc)
     return launch_passport_finish(part, N, C, gamma, b, alpha, margin, l2, dloss, dgamma_extra, dbeta_extra, m, K,
                                   dgamma, dbeta, dW, st);
 }

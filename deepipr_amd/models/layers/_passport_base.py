@@ -240,6 +240,29 @@ class PassportLayerBase(nn.Module):
                 sl.reset()
                 sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
             return y
+        passport_branch = not p_scale and not p_bias
+        inside = passport_branch and self._conv_inside(x)
+        if (inside and self.fuse_norm and self.bn is not None and not getattr(self.bn, 'affine', False)
+                and P.norm_groups(self.bn) and P.gn_supported_shape(self.bn, P.conv_out_shape(x, self.conv))):
+            # GroupNorm / InstanceNorm passport branch, data conv inside the fused node
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
+                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad, conv_inside=True)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
+        if inside and isinstance(self.bn, nn.Sequential) and len(self.bn) == 0:
+            # norm_type 'none': nothing between conv and affine -- the unfused pair of kernels, data conv inside the node
+            skey, key, m, stride, pad = self._pooled_means()
+            y, gamma, _beta, loss, acc, _bits = P.passport_layer(
+                x, self.weight, skey, key, sl.b if sl is not None else None, m,
+                sl.alpha if sl is not None else 0.0, relu, stride, pad, conv_inside=True)
+            if sl is not None:
+                sl.reset()
+                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+            return y
         x = self.conv(x)
         if self.fuse_norm and P.bn_is_fusable(self.bn) and p_scale == p_bias:
             # BatchNorm(affine=False) folded into the passport kernels: 3 launches forward, 3 backward,

@@ -192,20 +192,20 @@ class HipKernels:
 
     def passport_bwd(self, dy, xhat, gamma, beta, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu,
                      margin=MARGIN, l2=L2):
-        """-> dxhat, dW, dgamma, dbeta."""
+        """-> dxhat, dW (None when wshape is None: the caller accumulates it into the conv's wgrad), dgamma, dbeta."""
         dev = _chk(dy, xhat, gamma, beta, m, b, dloss, dgamma_extra, dbeta_extra)
         n, c = xhat.shape[0], xhat.shape[1]
         hw = xhat.numel() // (n * c)
         lib = _lib.lib()
         ws = torch.empty(lib.deepipr_passport_bwd_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
         dx = torch.empty_like(xhat)
-        dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         with _on(dev):
             _lib.check(lib.deepipr_passport_bwd(
                 _p(dy), _p(xhat), _p(gamma), _p(beta), _p(m), _p(b), alpha, margin, l2, _p(dloss),
-                _p(dgamma_extra), _p(dbeta_extra), n, c, hw, dw.numel() // c, int(relu), _p(dx), _p(dw),
-                _p(dgb[0]), _p(dgb[1]), _p(ws), _stream(dev)), 'passport_bwd')
+                _p(dgamma_extra), _p(dbeta_extra), n, c, hw, (dw.numel() // c) if dw is not None else 0, int(relu),
+                _p(dx), _p(dw), _p(dgb[0]), _p(dgb[1]), _p(ws), _stream(dev)), 'passport_bwd')
         return dx, dw, dgb[0], dgb[1]
 
 
@@ -615,6 +615,23 @@ class _SignLoss(torch.autograd.Function):
         return kernels.sign_loss_bwd(dloss.contiguous(), gamma, b, alpha, MARGIN, l2), None, None, None
 
 
+def _conv_fwd(x_in, w, stride, pad):
+    return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
+
+
+def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m):
+    """Backward of the data convolution that ran inside a fused passport node: MIOpen's dgrad / wgrad, then the passport
+    branch's rank-2 update added INTO that wgrad (deepipr_gamma_beta_bwd_acc).  -> dx_in, dW."""
+    need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if not (need_dx or need_dw):                      # frozen first layer: nothing flows further
+        return None, None
+    dx, dw, _ = torch.ops.aten.convolution_backward(
+        dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
+    if need_dw:
+        dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw.contiguous())
+    return dx, dw
+
+
 class _PassportLayer(torch.autograd.Function):
     """The fused passport layer after the norm: two launches forward, two backward.
 
@@ -623,11 +640,15 @@ class _PassportLayer(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xhat, weight, skey, key, b, m, alpha, relu, stride, pad):
+    def forward(ctx, xhat, weight, skey, key, b, m, alpha, relu, stride, pad, conv_inside=False):
         xhat, weight = xhat.contiguous(), weight.contiguous()
+        x_in = None
+        if conv_inside:                               # no norm between conv and affine: the data conv runs in this node
+            x_in = xhat
+            xhat = _conv_fwd(x_in, weight, stride, pad)
         bb = None if b is None else b.contiguous().view(-1)
         y, gamma, beta, loss, acc, bits = kernels.passport_fwd(xhat, weight, m, bb, float(alpha), relu)
-        ctx.save_for_backward(xhat, weight, gamma, beta, m, bb)
+        ctx.save_for_backward(xhat, weight, gamma, beta, m, bb, x_in)
         ctx.cfg = (float(alpha), relu, stride, pad, tuple(key.shape))
         ctx.set_materialize_grads(False)
         if bb is None:
@@ -638,19 +659,21 @@ class _PassportLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
-        xhat, weight, gamma, beta, m, bb = ctx.saved_tensors
+        xhat, weight, gamma, beta, m, bb, x_in = ctx.saved_tensors
         alpha, relu, stride, pad, key_shape = ctx.cfg
         if dy is None:
             dy = torch.zeros_like(xhat)
         dl = None if (bb is None or dloss is None) else dloss.contiguous()
         dx, dw, dg, db = kernels.passport_bwd(dy.contiguous(), xhat, gamma, beta, m, bb, alpha, dl,
                                               _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
-                                              weight.shape, relu)
+                                              None if x_in is not None else weight.shape, relu)
+        if x_in is not None:
+            dx, dw = _conv_bwd_acc(ctx, dx, x_in, weight, stride, pad, dg, db, m)
         dsk = dk = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             dsk, dk = kernels.gamma_beta_dkey(dg, db, weight, key_shape, stride, pad)
         return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class _PassportBNLayer(torch.autograd.Function):
@@ -675,7 +698,7 @@ class _PassportBNLayer(torch.autograd.Function):
         x_in = None
         if conv is not None:
             x_in = x
-            x = torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
+            x = _conv_fwd(x_in, w, stride, pad)
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
@@ -722,15 +745,7 @@ class _PassportBNLayer(torch.autograd.Function):
         dx, dw, dg, db = out[:4]
         dres = out[4] if ctx.tail else None
         if in_node_conv:
-            need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-            if need_dx or need_dw:
-                dx, dw, _ = torch.ops.aten.convolution_backward(
-                    dx, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
-                    [need_dx, need_dw, False])
-            else:                                         # frozen first layer: nothing flows further
-                dx = dw = None
-            if need_dw:
-                dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw.contiguous())
+            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m)
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
@@ -804,16 +819,20 @@ class _PassportGNLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, cfg):
-        alpha, relu, stride, pad, groups, eps = cfg
+        alpha, relu, stride, pad, groups, eps, conv_inside = cfg
         x = x.contiguous()
         w = None if weight is None else weight.contiguous()
+        x_in = None
+        if conv_inside:                               # the data convolution runs inside this node (see _PassportBNLayer)
+            x_in = x
+            x = _conv_fwd(x_in, w, stride, pad)
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
         y, stats, gamma, beta, loss, acc, bits = kernels.passport_gn_fwd(x, w, m, gi, bi, bb, float(alpha), relu,
                                                                          int(groups), float(eps))
         used_g, used_b = (gamma, beta) if w is not None else (gi, bi)
-        ctx.save_for_backward(x, w, stats, used_g, used_b, m, bb)
+        ctx.save_for_backward(x, w, stats, used_g, used_b, m, bb, x_in)
         ctx.cfg = (float(alpha), relu, stride, pad, int(groups), None if key is None else tuple(key.shape))
         ctx.set_materialize_grads(False)
         if gamma is None:
@@ -826,7 +845,7 @@ class _PassportGNLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dgamma_extra, dbeta_extra, dloss, _dacc, _dbits):
-        x, w, stats, g, bt, m, bb = ctx.saved_tensors
+        x, w, stats, g, bt, m, bb, x_in = ctx.saved_tensors
         alpha, relu, stride, pad, groups, key_shape = ctx.cfg
         if dy is None:
             dy = torch.zeros_like(x)
@@ -835,7 +854,9 @@ class _PassportGNLayer(torch.autograd.Function):
             dgamma_extra = dbeta_extra = None
         dx, dw, dg, db = kernels.passport_gn_bwd(dy.contiguous(), x, stats, g, bt, m, bb, alpha, dl,
                                                  _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
-                                                 None if w is None else w.shape, relu, groups)
+                                                 None if (w is None or x_in is not None) else w.shape, relu, groups)
+        if x_in is not None:
+            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m)
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
@@ -863,15 +884,23 @@ def gn_is_fusable(norm, x):
     return kernels.gn_supported(n, c, x.numel() // (n * c), groups)
 
 
-def passport_gn_layer(x, weight, skey, key, b, m, norm, alpha, relu, stride, pad):
-    """Fused passport branch on the conv output `x`; `norm` is the layer's GroupNorm / InstanceNorm2d (affine=False)."""
-    cfg = (alpha, bool(relu), stride, pad, norm_groups(norm), norm.eps)
+def gn_supported_shape(norm, shape):
+    """gn_is_fusable for a conv output that does not exist yet: `shape` = (N, C, H, W)."""
+    groups = norm_groups(norm)
+    n, c, h, w = shape
+    return bool(groups) and kernels.gn_supported(n, c, h * w, groups)
+
+
+def passport_gn_layer(x, weight, skey, key, b, m, norm, alpha, relu, stride, pad, conv_inside=False):
+    """Fused passport branch on the conv output `x` (conv_inside: on the layer's input, the data conv runs inside
+    the node); `norm` is the layer's GroupNorm / InstanceNorm2d (affine=False)."""
+    cfg = (alpha, bool(relu), stride, pad, norm_groups(norm), norm.eps, bool(conv_inside))
     return _PassportGNLayer.apply(x, weight, skey, key, None, None, b, m, cfg)
 
 
 def gn_affine_relu(x, gamma, beta, norm, relu=True):
     """Fused W-less branch: GroupNorm / InstanceNorm2d + per-channel gamma/beta (None = 1 / 0) + ReLU."""
-    cfg = (0.0, bool(relu), 1, 0, norm_groups(norm), norm.eps)
+    cfg = (0.0, bool(relu), 1, 0, norm_groups(norm), norm.eps, False)
     return _PassportGNLayer.apply(x, None, None, None, gamma, beta, None, None, cfg)[0]
 
 
@@ -985,5 +1014,7 @@ def sign_loss(gamma, b, alpha, l2=L2):
     return _SignLoss.apply(gamma, b, alpha, l2)
 
 
-def passport_layer(xhat, weight, skey, key, b, m, alpha, relu, stride, pad):
-    return _PassportLayer.apply(xhat, weight, skey, key, b, m, alpha, bool(relu), stride, pad)
+def passport_layer(xhat, weight, skey, key, b, m, alpha, relu, stride, pad, conv_inside=False):
+    """conv_inside (only when NO norm sits between conv and affine): `xhat` is the layer's input, the data conv runs
+    inside the node and the shared weight's gradient is accumulated in place."""
+    return _PassportLayer.apply(xhat, weight, skey, key, b, m, alpha, bool(relu), stride, pad, bool(conv_inside))

@@ -154,7 +154,9 @@ int deepipr_passport_fwd(const float *xhat, const float *W, const double *m,
 /* Backward of the same: launch 1 = affine backward (dxhat + per-split partial sums), launch 2 =
  * finish the partial sums, add dgamma_extra / dbeta_extra (gradients arriving at gamma / beta from
  * elsewhere, may be NULL) and the sign-loss gradient (scaled by the device scalar *dloss, NULL = no sign loss), write
- * dgamma/dbeta and the rank-2 update dW.  workspace: deepipr_passport_bwd_workspace_bytes(). */
+ * dgamma/dbeta and the rank-2 update dW.  dW == NULL: dgamma / dbeta only (sign-loss gradient and extras included);
+ * the caller then adds the rank-2 update to the data convolution's wgrad with deepipr_gamma_beta_bwd_acc (same for
+ * deepipr_passport_gn_bwd).  workspace: deepipr_passport_bwd_workspace_bytes(). */
 size_t deepipr_passport_bwd_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma, const float *beta,
                          const double *m, const float *b, float alpha, float margin, float l2,

@@ -84,7 +84,7 @@ class OracleKernels:
             db = db + dbeta_extra
         if dloss is not None:
             dg = dg + self.sign_loss_bwd(dloss, gamma, b, alpha, margin, l2)
-        return dx, self.gamma_beta_bwd(dg, db, m, wshape), dg, db
+        return dx, (self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None), dg, db
 
     # ---- BatchNorm-fused entry points: stock ATen batch_norm on the host as the checker ----
     allow_sync = True
