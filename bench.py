@@ -385,7 +385,7 @@ def main():
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
                  'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',
-                 'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt; 20-24 with a folded residual tail)',
+                 'bn_res_bwd': 'single-pass norm+affine+ReLU backward: read dy + x once, write dx (12 B/elt; 16 with a second incoming gradient; 20-24 with a folded residual tail)',
                  'bn_res_fwd': 'single-pass norm+affine+ReLU forward: read x once, write y (8 B/elt; 12 with a folded residual tail)',
                  'bn_affine_bwd': 'norm+affine+ReLU backward apply pass: read dy + x, write dx (12 B/elt)',
                  'bn_affine_fwd': 'norm+affine+ReLU forward apply pass (8 B/elt)',
