@@ -102,6 +102,9 @@ class GraphedTrainStep:
                     self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
         finally:
             kernels.allow_sync = saved_allow
+        # the gradient tensors the replayed backward writes (graph-pool memory): `.grad` must point at them whenever the
+        # optimiser runs OUTSIDE the graph, also after an eager step in between (a ragged last batch) re-bound it
+        self._captured_grads = [(p, p.grad) for g in optimizer.param_groups for p in g['params']]
 
     def _dry_run(self, step_fn, model, optimizer):
         base = model
@@ -138,5 +141,7 @@ class GraphedTrainStep:
         self.static_target.copy_(target, non_blocking=True)
         self.graph.replay()
         if not self.optimizer_in_graph:
+            for p, g in self._captured_grads:
+                p.grad = g
             self.optimizer.step()
         return self.outputs

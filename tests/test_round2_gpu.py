@@ -575,3 +575,31 @@ def test_fused_cross_entropy_and_top1(K, n, c):
     g_ref = xr.grad.numpy()
     assert np.abs(host(x.grad) - g_ref).max() <= 1e-6 * max(1e-3, np.abs(g_ref).max())
     assert not top1.requires_grad
+
+
+@pytest.mark.miopen_pinned
+def test_replay_with_eager_optimizer_survives_an_eager_step_in_between(K):
+    """Data-parallel form of the graphed step (forward + backward replayed, optimiser eager): a ragged last batch runs
+    the eager step, which re-binds every `.grad`; the next replay's optimiser step must still use the gradients the
+    replayed backward wrote.  Trajectory == all-eager."""
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from tests.test_parity_gpu import _fullsize_pair
+    finals = []
+    for graphed in (False, True):
+        prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+        x, y = x.to(DEV), y.to(DEV)
+        opt = torch.optim.SGD(prod.parameters(), **SGD)
+        seq = [(x, y), (x[:20], y[:20]), (x.flip(0), y.flip(0)), (x, y)]           # the second batch is ragged
+        with pinned_miopen():
+            g = GraphedTrainStep(train_step_v1, prod, opt, x, y, warmup=0, optimizer_in_graph=False) if graphed else None
+            for xb, yb in seq:
+                if graphed and xb.shape[0] == x.shape[0]:
+                    g(xb, yb)
+                else:
+                    train_step_v1(prod, opt, xb, yb)
+            torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in prod.state_dict().items()})
+    for k in finals[0]:
+        if finals[0][k].dtype.is_floating_point:
+            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
