@@ -349,7 +349,7 @@ def test_set_b_changes_the_fused_training_loss(K):
         blk.sign_loss.alpha = 0.25
         blk(x)
         want = float((0.25 * torch.relu(-newb * gamma + 0.1)).sum() + 1e-5 * gamma.pow(2).sum())
-        assert float(blk.sign_loss.loss) == pytest.approx(want, rel=1e-5), norm
+        assert float(blk.sign_loss.loss.detach()) == pytest.approx(want, rel=1e-5), norm
         assert float(blk.sign_loss.acc) == 0.0
 
 
