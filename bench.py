@@ -282,8 +282,8 @@ def main():
     # dual-forward V2/V3 step); eager enqueue costs 4.5-9 ms of host time against 5.1-5.6 ms of GPU time, so an eager
     # step is host-bound exactly where it matters most (32 images per GPU in config P).
     #   one GPU      : the whole step (zero_grad .. optimiser) is one graph;
-    #   several GPUs : zero_grad .. backward is one graph; FlatSGD's bucketed RCCL all-reduces and the fused SGD
-    #                  kernel are enqueued eagerly after each replay (no collective is ever captured).  The exchange
+    #   several GPUs : zero_grad .. backward is one graph; FlatSGD's RCCL all-reduce of the flat gradient buffer and the
+    #                  fused SGD kernel are enqueued eagerly after each replay (no collective is ever captured).  The exchange
     #                  (44.7 MB, ~0.5 ms over xGMI at N = 8) is then not hidden behind backward, but the step no
     #                  longer waits for the host -- measured on one GPU with the exchange forced on
     #                  (DEEPIPR_FORCE_DDP=1): see DESIGN.md 5.
@@ -377,10 +377,10 @@ def main():
                                     '' if args.norm_type == 'bn' else ', norm_type ' + args.norm_type) + (
                                     ', library norm kernels (--no-fuse)' if args.no_fuse else ''),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
-                   'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, bucketed RCCL all-reduce)',
+                   'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, RCCL all-reduce: one message after a replayed backward, four gradient-ready buckets with --eager)',
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': (('hipGraph replay of %s; kernel timing from %d eager steps right after the timed region'
-                               % ('the whole step' if not tdist_on else 'zero_grad..backward, then eager bucketed '
+                               % ('the whole step' if not tdist_on else 'zero_grad..backward, then one eager '
                                   'all-reduce + fused SGD', sampled)) if use_graph else 'eager')},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',

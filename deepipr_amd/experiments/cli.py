@@ -44,7 +44,7 @@ def make_parser(private):
                    help='DistributedDataParallel + torch SGD instead of the default FlatSGD data parallelism')
     p.add_argument('--graph', action='store_true', default=False,
                    help='replay the train step from a captured hipGraph (the default with several GPUs: forward + '
-                        'backward are replayed, the bucketed gradient exchange and the fused SGD run after each replay)')
+                        'backward are replayed, one all-reduce of the flat gradient buffer and the fused SGD run after each replay)')
     p.add_argument('--eager', action='store_true', default=False,
                    help='eager dispatch also with several GPUs (gradient exchange overlapped with backward)')
     return p

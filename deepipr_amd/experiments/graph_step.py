@@ -1,10 +1,11 @@
-"""hipGraph capture of a whole train step (single GPU).
+"""hipGraph capture of a train step.
 
 At the reference's small per-GPU batches (config P: 32 images per GPU, two forwards per step) the step is
-host-bound: ~1 000 kernel launches of a few microseconds each.  Capturing zero_grad -> forward -> losses ->
-backward -> SGD once and replaying it removes the launch overhead; the passport kernels are capture-safe by
-contract (enqueue-only C ABI, caller-provided workspaces, no host reads).  At batch 128 the step is GPU-bound
-and the graph buys nothing (6.67 vs 6.69 ms), so it is opt-in.
+host-bound: several hundred kernel launches of a few microseconds each.  Capturing zero_grad -> forward -> losses ->
+backward (-> SGD on one GPU) once and replaying it removes the launch overhead; the passport kernels are capture-safe
+by contract (enqueue-only C ABI, caller-provided workspaces, no host reads).  Measured on one MI355X:
+config-P shard 10.7 ms eager -> 5.0 ms replayed; config R (128 images) 5.8 -> 5.5 ms.  bench.py replays by default;
+the trainers do with several GPUs (--graph on one).
 
 Constraints while a graphed step is in use: static batch shape; passport keys must not change (the pooled
 key means are cached outside the graph); in-situ kernel timing (deepipr_profile_enable) must stay off.

@@ -119,7 +119,12 @@ class FlatSGD(torch.optim.Optimizer):
         """Gradients of bucket b -> their slots of flat_grad with ONE cat kernel (alignment pads and parameters
         that received no gradient are filled from a zero buffer)."""
         lo, hi = self._buckets[b]
-        start, end = self._range(b)
+        self._pack_slots(lo, hi)
+
+    def _pack_slots(self, lo, hi):
+        start = self._slots[lo][1]
+        last_p, last_off = self._slots[hi - 1]
+        end = last_off + (last_p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         pieces = []
         for p, off in self._slots[lo:hi]:
             n = p.numel()
@@ -196,11 +201,19 @@ class FlatSGD(torch.optim.Optimizer):
         missing = self._missing_grads()
         if capturing and not self.comm and not missing and self._step_in_place():
             return loss                                   # gradients read where autograd left them: no packing pass
-        for b in range(len(self._buckets)):
-            if not self._launched[b]:
-                self._launch(b, async_op=False)
-        for w in self._works:
-            w.wait()
+        if not any(self._launched):
+            # No bucket left from a gradient hook -- one GPU, or the backward was a replayed hipGraph (hooks paused
+            # at capture, nothing to overlap with any more): ONE pack and ONE all-reduce of the whole buffer.  xGMI
+            # is point-to-point and per-link bound, so one 44.7 MB ring pass beats four of 19 / 15 / 8.5 / 2.7 MB.
+            self._pack_slots(0, len(self._slots))
+            if self.comm:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for b in range(len(self._buckets)):
+                if not self._launched[b]:
+                    self._launch(b, async_op=False)
+            for w in self._works:
+                w.wait()
         if not missing:
             P.kernels.sgd_momentum_step_dev(self.flat_param, self.flat_grad, self.flat_buf, self._hyper)
         else:

@@ -82,6 +82,27 @@ def _worker(rank, world, port, private, out_dir, flat=False):
     x, y = _batch()
     lo, hi = rank * 4, rank * 4 + 4
     step = train_step_v23 if private else train_step_v1
+    if flat == 'replay':
+        # what a replayed hipGraph of forward + backward leaves behind (experiments/graph_step.py, data-parallel
+        # mode): gradients, no hook ever fired, the optimiser runs eagerly afterwards -- one all-reduce per step
+        from deepipr_amd.experiments.graph_step import _NoStep
+        inner, calls, real_all_reduce = step, [], dist.all_reduce
+
+        def counted(t, *a, **k):
+            calls.append(t.numel())
+            return real_all_reduce(t, *a, **k)
+
+        def step(wrapped, opt, xs, ys):
+            with opt.pause_hooks():
+                out = inner(wrapped, _NoStep(opt), xs, ys)
+            dist.all_reduce = counted
+            try:
+                opt.step()
+            finally:
+                dist.all_reduce = real_all_reduce
+            assert calls == [opt.flat_grad.numel()], calls
+            calls.clear()
+            return out
     out = step(wrapped, opt, x[lo:hi], y[lo:hi])
     if flat:                                       # a second step exercises momentum and the bucket bookkeeping
         out2 = step(wrapped, opt, x[lo:hi].flip(0), y[lo:hi].flip(0))
@@ -91,7 +112,7 @@ def _worker(rank, world, port, private, out_dir, flat=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('flat', [False, True])
+@pytest.mark.parametrize('flat', [False, True, 'replay'])
 @pytest.mark.parametrize('private', [False, True])
 def test_two_rank_step_equals_single_process_step(private, flat, tmp_path, monkeypatch):
     port = _free_port()
