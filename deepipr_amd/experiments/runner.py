@@ -232,4 +232,4 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
             print('epoch %d done in %.2fs: %s' % (ep, time.time() - t0, {k: round(v, 4) if isinstance(v, float)
                                                                          else v for k, v in row.items()}))
         D.barrier()
-    return {'logdir': logdir, 'history': history}
+    return {'logdir': logdir, 'history': history, 'model': model}

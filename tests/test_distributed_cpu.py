@@ -163,3 +163,46 @@ def test_replicate_refuses_unset_keys():
                                               'key_type': 'random', 'sl_ratio': 0.1})
     with pytest.raises(RuntimeError, match='passport keys'):
         D.check_keys_materialised(AlexNetPassport(3, 10, kw))
+
+
+def _entry_worker(rank, world, port, private, ddp, logdir):
+    sys.path.insert(0, ROOT)
+    os.chdir(ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from deepipr_amd import passport_ops
+    from tests.oracle_kernels import OracleKernels
+    passport_ops.kernels = OracleKernels()
+    import train_v1
+    import train_v23
+    argv = ['--arch', 'alexnet', '--key-type', 'random', '--epochs', '2', '--batch-size', '8',
+            '--synthetic-samples', '16', '--device', 'cpu', '--backend', 'gloo', '--logdir', logdir, '--norm-type', 'none']
+    argv += ['--train-backdoor'] if private else ['--train-passport']
+    argv += ['--ddp'] if ddp else []
+    out = (train_v23 if private else train_v1).main(argv)
+    torch.save({'logdir': out['logdir'], 'rows': len(out['history']),
+                'state': {k: v.clone() for k, v in out['model'].state_dict().items()}},
+               os.path.join(logdir, 'entry_rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('private,ddp', [(False, False), (True, False), (False, True)])
+def test_entry_points_with_two_ranks(private, ddp, tmp_path):
+    """train_v1.py / train_v23.py --train-backdoor as two gloo ranks (the flow torchrun starts on a multi-GPU node):
+    process-group set-up from the environment, rank-0 state broadcast, sharded synthetic loaders, FlatSGD's (or DDP's)
+    gradient exchange, rank-0-only evaluation and checkpoints between barriers, the experiment id agreed by broadcast."""
+    port = _free_port()
+    mp.spawn(_entry_worker, args=(2, port, private, ddp, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'entry_rank0.pt')
+    r1 = torch.load(tmp_path / 'entry_rank1.pt')
+    assert r0['logdir'] == r1['logdir'] and r0['logdir'].endswith(os.sep + '1')
+    assert r0['rows'] == 2 and r1['rows'] == 0                  # history and checkpoints are rank 0's
+    assert os.path.exists(os.path.join(r0['logdir'], 'history.csv'))
+    # the gradient exchange kept the replicas in lock step over both epochs (norm_type 'none': no per-rank statistics),
+    # and what rank 0 saved is that state
+    saved = torch.load(os.path.join(r0['logdir'], 'models', 'last.pth'))
+    assert any(k.endswith('key') or k.endswith('key_private') for k in saved)
+    for k, v in r0['state'].items():
+        assert torch.equal(v, r1['state'][k]), k
+        assert torch.equal(v, saved[k]), k
