@@ -1351,16 +1351,6 @@ __device__ __forceinline__ void res_stamp(const ResPlan &pl, int slot) {
 #endif
 }
 
-__device__ __forceinline__ void sc1_store(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ double sc1_load(const double *p) {
-    return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
-        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-}
-
 // Per-local-channel sums of (a, b) over the workgroup; every thread gets the sums of ITS channel.
 // red: 2 * (T/64) * 8 doubles of LDS.
 template <int T>
@@ -3069,7 +3059,7 @@ int deepipr_passport_gn_bwd(const float *dy, const float *x, const float *stats,
         prof.bytes = 12.0 * static_cast<double>(N) * C * HW;
         const int cpb = pl.T / pl.TG;
         const dim3 grid((pl.chunks + cpb - 1) / cpb);
-        const size_t lds = static_cast<size_t>(cpb) * pl.U * 2 * sizeof(float);
+        const unsigned lds = static_cast<unsigned>(static_cast<size_t>(cpb) * pl.U * 2 * sizeof(float));
         const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
         float4 *o4 = reinterpret_cast<float4 *>(dx);
         if (prof.a) {
