@@ -84,3 +84,18 @@ def test_kernels_do_not_spill_registers(tmp_path):
     assert len(names) == len(scratch) and len(names) > 100
     spilled = {n: s for n, s in zip(names, scratch) if s}
     assert not spilled, spilled
+
+
+def test_integration_stub_matches_the_abi():
+    """INTEGRATION.md section B shows the ctypes binding a maintainer of the reference would add: its argtypes lines
+    must be the header's signatures (same arity, same pointer / int / float kind per argument)."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    lines = re.findall(r'^_L\.(deepipr_[a-z0-9_]+)\.argtypes = (.+)$', text, flags=re.M)
+    assert {n for n, _ in lines} >= {'deepipr_pooled_patch_mean', 'deepipr_passport_fwd', 'deepipr_passport_bwd'}
+    env = {'_vp': ctypes.c_void_p, '_i': ctypes.c_int, '_f': ctypes.c_float}
+    for name, expr in lines:
+        stub = eval(expr, {'__builtins__': {}}, env)
+        assert stub == _lib.SIGNATURES[name][1], name
+    # every entry point the stub calls is declared
+    for name in set(re.findall(r'_L\.(deepipr_[a-z0-9_]+)', text)):
+        assert name in _lib.SIGNATURES, name
