@@ -1,0 +1,90 @@
+"""Runs INTEGRATION.md section B's reference-side ctypes stub on the GPU, as a maintainer of the reference would use it.
+
+Not collected by pytest (no test_ prefix): written at the end of round 2 without GPU time left to validate it -- run it
+once (`python tests/triage/integration_stub_gpu.py`, expect "stub ok"), then move it into tests/test_parity_gpu.py.
+
+What it does: extracts the stub's code block from INTEGRATION.md, points it at the in-tree library and drives
+`PassportAffine` + `pooled` forward and backward on a stride-2 3x3 block; the same inputs go through the product's
+own binding (deepipr_amd.passport_ops.kernels) -- the two bindings call the same kernels, so every output must be
+bit-identical -- and through a stock-ATen composition of models/layers/passportconv2d.py:140-172,218-223 +
+models/losses/sign_loss.py:27,53 in float64 (1e-5 of scale).
+"""
+import os
+import re
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def stub_namespace():
+    from deepipr_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    code = next(b for b in blocks if b.lstrip().startswith('# models/layers/_deepipr_hip.py'))
+    assert '/path/to/libdeepipr_hip.so' in code
+    ns = {}
+    exec(compile(code.replace('/path/to/libdeepipr_hip.so', _lib.LIB_PATH), 'INTEGRATION.md#B', 'exec'), ns)
+    return ns
+
+
+def main():
+    from deepipr_amd import passport_ops
+    K = passport_ops.kernels
+    ns = stub_namespace()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    n, ci, co, hin, alpha = 8, 16, 32, 16, 0.1
+    conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).to(dev)
+    W = (0.1 * torch.randn(co, ci, 3, 3, generator=g)).to(dev)
+    key = torch.randn(1, ci, hin, hin, generator=g).to(dev)
+    skey = torch.randn(1, ci, hin, hin, generator=g).to(dev)
+    b = torch.sign(torch.randn(co, generator=g)).to(dev)
+    xhat = torch.randn(n, co, hin // 2, hin // 2, generator=g).to(dev)
+    cot = torch.randn(n, co, hin // 2, hin // 2, generator=g).to(dev)
+
+    # (1) the stub
+    w1 = W.clone().requires_grad_(True)
+    x1 = xhat.clone().requires_grad_(True)
+    m1 = ns['pooled'](skey, key, conv)
+    y1, gamma1, loss1, acc1, bits1 = ns['PassportAffine'].apply(x1, w1, m1, b, alpha, True)
+    ((y1 * cot).sum() + loss1).backward()
+
+    # (2) the product's binding of the same entry points
+    m2 = K.pooled_patch_mean(torch.stack([skey, key]).contiguous(), 3, 3, 2, 1)
+    y2, gamma2, beta2, loss2, acc2, bits2 = K.passport_fwd(xhat, W, m2, b, alpha, True)
+    one = torch.ones((), device=dev)
+    dx2, dw2, _dg, _db = K.passport_bwd(cot.contiguous(), xhat, gamma2, beta2, m2, b, alpha, one, None, None,
+                                        tuple(W.shape), True)
+    for name, a, c in (('m', m1, m2), ('y', y1, y2), ('gamma', gamma1, gamma2), ('loss', loss1, loss2),
+                       ('acc', acc1, acc2), ('bits', bits1, bits2), ('dx', x1.grad, dx2), ('dW', w1.grad, dw2)):
+        assert torch.equal(a.detach(), c.detach()), 'stub vs product binding: %s' % name
+
+    # (3) stock ATen in float64, written the way the reference's layer computes it
+    w3 = W.double().clone().requires_grad_(True)
+    x3 = xhat.double().clone().requires_grad_(True)
+    F = torch.nn.functional
+    gamma3 = F.conv2d(skey.double(), w3, None, 2, 1).view(1, co, -1).mean(dim=2).view(1, co, 1, 1)
+    beta3 = F.conv2d(key.double(), w3, None, 2, 1).view(1, co, -1).mean(dim=2).view(1, co, 1, 1)
+    y3 = torch.relu(gamma3 * x3 + beta3)
+    hinge3 = (alpha * torch.relu(-gamma3.view(-1) * b.double() + 0.1)).sum()       # sign_loss.py:27
+    loss3 = hinge3 + 1e-5 * (gamma3 ** 2).sum()                                      # sign_loss.py:53
+    ((y3 * cot.double()).sum() + loss3).backward()
+
+    def close(name, a, ref, tol=1e-5):
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((a.double() - ref).abs().max())
+        assert err <= tol * scale, '%s: %g > %g' % (name, err, tol * scale)
+    close('y', y1.detach(), y3.detach())
+    close('gamma', gamma1.detach(), gamma3.detach().view(-1))
+    close('dx', x1.grad, x3.grad)
+    close('dW', w1.grad, w3.grad, tol=1e-4)
+    assert torch.equal(bits1.cpu().to(torch.float64), torch.sign(gamma3.detach().view(-1)).cpu())
+    assert abs(float(loss1.detach()) - float(loss3.detach())) <= 1e-5 * max(1.0, abs(float(loss3.detach())))
+    print('stub ok: 8 outputs bit-identical with the product binding, 5 within 1e-5 of stock ATen (f64)')
+
+
+if __name__ == '__main__':
+    main()
