@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the DeepIPR passport train step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -203,6 +203,42 @@ def pmc_traffic(kernel, shape_key, algorithmic=None):
         return None
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` typed without a launcher (the reference's multi-GPU entry is one command too,
+    experiments/trainer.py:92-93): re-execute under torch.distributed.run with N ranks on this node, rendezvous on
+    127.0.0.1 and a free port; rank 0's JSON line passes through on stdout, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """--dry-run: the launch plumbing only (rendezvous, barrier, max-over-ranks, one JSON line from rank 0), on any
+    backend and without a GPU -- what tests/test_bench_helpers.py runs in the CPU container.  No workload, no value."""
+    import torch.distributed as dist
+    rank, _local, world = D.init_from_env(args.backend)
+    t0 = time.perf_counter()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    dev = torch.device('cpu') if (args.backend == 'gloo' or not torch.cuda.is_available()) else torch.device('cuda', _local)
+    dt = D.max_over_ranks(dt, dev)
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run: launcher and process group only', 'value': None, 'unit': 'img/s',
+                          'n_gpus': args.gpus, 'world_size_seen': seen, 'steps': 0, 'warmup': 0, 'dry_run': True,
+                          'barrier_s': round(dt, 4)}), flush=True)
+    D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -224,19 +260,32 @@ def main():
     ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
     ap.add_argument('--ddp-static-graph', type=int, default=1, help='DistributedDataParallel(static_graph=...)')
     ap.add_argument('--verbose', action='store_true', help='phase progress with timestamps on stderr')
+    ap.add_argument('--unstaged', action='store_true', help='N > 1: forward + backward as ONE graph, the whole exchange '
+                    'after it (round-2 form) instead of the staged, overlapped exchange')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    ap.add_argument('--dry-run', action='store_true', help='launch plumbing only: no workload (CPU-testable)')
     args = ap.parse_args()
     t_start = time.perf_counter()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and os.environ.get('DEEPIPR_FORCE_DDP') != '1':
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    if args.dry_run:
+        return dry_run(args)
 
     def note(msg):
         if args.verbose:
             print('bench.py [%7.1f s] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    rank, local_rank, world = D.init_from_env()
+    rank, local_rank, world = D.init_from_env(args.backend)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)' % (args.gpus, world))
-        args.gpus = world
+        args.gpus = world                                 # a launcher's WORLD_SIZE wins over --gpus
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+    if local_rank >= torch.cuda.device_count():
+        # rehearsal of the N > 1 path on a box with fewer GPUs (ranks share devices; RCCL refuses that, so it needs
+        # --backend gloo): correctness of the exchange plumbing only, the timing means nothing
+        if os.environ.get('DEEPIPR_SHARE_GPU') != '1':
+            raise SystemExit('rank %d: only %d GPU(s) visible (DEEPIPR_SHARE_GPU=1 --backend gloo shares them for a '
+                             'functional rehearsal)' % (local_rank, torch.cuda.device_count()))
+        local_rank %= torch.cuda.device_count()
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find-mode, as train_v1.py:8
@@ -295,7 +344,13 @@ def main():
             from deepipr_amd.experiments.graph_step import GraphedTrainStep
             fn = train_step_v1 if args.scheme == 1 else train_step_v23
             import torch.distributed as tdist
-            graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
+            if tdist.is_initialized() and not args.unstaged:
+                # data parallel: backward cut into stages at the gradient buckets' boundaries, one hipGraph per stage,
+                # bucket k's RCCL all-reduce on a side stream while stage k + 1 replays (experiments/staged.py)
+                from deepipr_amd.experiments.staged import StagedStep
+                graphed = StagedStep(fn, net, opt, xs[0], ys[0], graph=True)
+            else:
+                graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
             step = lambda i: graphed(xs[i % nb], ys[i % nb])
         except Exception as exc:                           # capture refused: measure the eager step instead
             print('bench.py: hipGraph capture failed (%s: %s); timing the eager step' % (type(exc).__name__, exc),
@@ -348,6 +403,20 @@ def main():
     if timing:
         _lib.profile_enable(False)
     dt = D.max_over_ranks(dt, device)
+    # exposed part of the gradient exchange (staged mode): GPU time between the end of the last backward stage and the
+    # SGD kernel -- pack + all-reduce of the buckets that could not travel under backward + the waits -- from events on
+    # 20 extra steps after the timed region (max over ranks).  None when no exchange runs.
+    exposed_us, stage_plan = None, None
+    if use_graph and tdist_on and hasattr(graphed, 'describe'):
+        stage_plan = graphed.describe()
+        opt.exposed_events = []
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize()
+        if opt.exposed_events:
+            exposed_us = 1000.0 * sum(a.elapsed_time(b) for a, b in opt.exposed_events) / len(opt.exposed_events)
+            exposed_us = D.max_over_ranks(exposed_us, device)
+        opt.exposed_events = None
 
     # signature read-out after the run: sign(gamma) == b per passport layer (experiments/trainer_private.py:37-71)
     from deepipr_amd.experiments.trainer_private import TesterPrivate
@@ -369,6 +438,8 @@ def main():
         'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
         # bounded in-kernel waits of the single-pass kernels' partial-sum exchange that ever expired (must be 0)
         'exchange_timeouts': _exchange_timeouts(),
+        'world_size_seen': (_td.get_world_size() if tdist_on else 1),
+        'exchange_us_exposed': None if exposed_us is None else round(exposed_us, 1),
         'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '
                                 '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                 ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
@@ -377,11 +448,14 @@ def main():
                                     '' if args.norm_type == 'bn' else ', norm_type ' + args.norm_type) + (
                                     ', library norm kernels (--no-fuse)' if args.no_fuse else ''),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
-                   'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers, RCCL all-reduce: one message after a replayed backward, four gradient-ready buckets with --eager)',
+                   'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers; RCCL all-reduce of the gradient buckets between the replayed backward stages, or from gradient hooks with --eager)',
+                   'exchange': stage_plan,
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': (('hipGraph replay of %s; kernel timing from %d eager steps right after the timed region'
-                               % ('the whole step' if not tdist_on else 'zero_grad..backward, then one eager '
-                                  'all-reduce + fused SGD', sampled)) if use_graph else 'eager')},
+                               % ('the whole step' if not tdist_on else ('zero_grad..backward, then one eager '
+                                  'all-reduce + fused SGD' if args.unstaged else 'the staged step (one graph per '
+                                  'backward stage, bucket all-reduces in between, fused SGD)'), sampled))
+                              if use_graph else 'eager')},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',
                  'gn_fwd': 'GroupNorm/InstanceNorm+affine+ReLU forward, register-resident (8 B/elt)',

@@ -31,6 +31,8 @@ SIGNATURES = {
     'deepipr_gamma_beta_fwd': (_int, [_f32p, _f64p, _int, _int, _f32p, _f32p, _vp]),
     'deepipr_gamma_beta_bwd': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
     'deepipr_gamma_beta_bwd_acc': (_int, [_f32p, _f32p, _f64p, _int, _int, _f32p, _vp]),
+    'deepipr_gamma_beta_fwd_multi': (_int, [_vp, _int, _vp]),
+    'deepipr_gamma_beta_bwd_multi': (_int, [_vp, _int, _int, _vp]),
     'deepipr_gamma_beta_dkey_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_gamma_beta_dkey': (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _f32p, _vp, _vp]),
@@ -66,6 +68,7 @@ SIGNATURES = {
                                        _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _vp,
                                        _vp, _f32p, _f32p, _f32p, _vp]),
     'deepipr_passport_bn_resident': (_int, [_int, _int, _int, _int]),
+    'deepipr_passport_bn_slices': (_int, [_int, _int, _int]),
     'deepipr_passport_gn_supported': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_gn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _flt, _int,
@@ -76,9 +79,20 @@ SIGNATURES = {
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 SYNC_WORDS = 2 * 256 * 30 * 4 + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * 256 * 30 * 4   # DEEPIPR_SYNC_TIMEOUT_WORD
+
+
+GEMV_MAX_LAYERS = 16                    # DEEPIPR_GEMV_MAX_LAYERS
+
+
+class GemvLayer(_c.Structure):          # DeepiprGemvLayer
+    _fields_ = [('W', _vp), ('m', _vp), ('gamma', _vp), ('beta', _vp), ('Co', _int), ('K', _int)]
+
+
+class Rank2Layer(_c.Structure):         # DeepiprRank2Layer
+    _fields_ = [('dgamma', _vp), ('dbeta', _vp), ('m', _vp), ('dW', _vp), ('Co', _int), ('K', _int)]
 
 
 class HipLibraryMissing(RuntimeError):

@@ -45,6 +45,8 @@ constexpr int kRowPairMinCo = 256;     // W rows are processed two per workgroup
 
 thread_local char g_err[512] = "";
 
+int device_cu_count();                  // defined with the single-pass planner below
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -333,6 +335,171 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta_bwd(
         db[r] = dbeta[co];
     }
     write_dw_rows<VEC, RPW, ACC>(dW, s, Co, K, co0, dg, db);
+}
+
+// ---- batched / deep-pipelined form -------------------------------------------------------------------------
+// One launch computes gamma and beta of up to kGemvMaxLayers passport layers (ResNet18: the five layer4 weights,
+// 33.6 MB): grid = sum over layers of ceil(Co / RPW) workgroups, the per-layer descriptors travel by value in the
+// kernel arguments (no device table to maintain; frozen with the launch in a hipGraph).  Round 2 launched one
+// k_gamma_beta per layer with ONE 4-wave workgroup per CU, whose threads walked K/1024 dependent trips of two float4
+// loads: 5 us per 9.4 MB weight = 0.17 of the HBM roofline, latency- not bandwidth-bound (PMC: 1.07x the algorithmic
+// bytes).  Here every thread issues ALL its loads of W (kGemvPre float4 per row, K <= 5120 in one trip) before the first
+// FMA, and the batch puts 5-10 workgroups on every CU.
+constexpr int kGemvMaxLayers = 16;
+constexpr int kGemvPre = 5;
+
+struct GemvLayer {
+    const float *W;
+    const double *m;            // [2][K] pooled patches (scale key, bias key)
+    float *gamma, *beta;
+    int Co, K, block0, vec;     // first workgroup of this layer; vec: K % 4 == 0 and 16-byte aligned rows
+};
+struct GemvBatch {
+    GemvLayer L[kGemvMaxLayers];
+    int n;
+};
+
+template <int RPW>
+__device__ __forceinline__ void gemv_rows_pre(const float *__restrict__ W, const double *__restrict__ s, int Co, int K,
+                                              int co0, double (&as)[RPW], double (&ab)[RPW]) {
+    const double2 *ss2 = reinterpret_cast<const double2 *>(s);
+    const double2 *sb2 = reinterpret_cast<const double2 *>(s + K);
+    const float4 *row[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = 0.0;
+        ab[r] = 0.0;
+        row[r] = reinterpret_cast<const float4 *>(W + static_cast<size_t>(min(co0 + r, Co - 1)) * K);
+    }
+    const int K4 = K / 4;
+    for (int base = 0; base < K4; base += kGemvPre * kThreads) {
+        float4 w[RPW][kGemvPre];
+#pragma unroll
+        for (int p = 0; p < kGemvPre; ++p) {
+            const int q = base + p * kThreads + static_cast<int>(threadIdx.x);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) w[r][p] = q < K4 ? row[r][q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int p = 0; p < kGemvPre; ++p) {
+            const int q = base + p * kThreads + static_cast<int>(threadIdx.x);
+            if (q < K4) {
+                const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
+                const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    as[r] = fma(static_cast<double>(w[r][p].x), s0.x, as[r]);
+                    as[r] = fma(static_cast<double>(w[r][p].y), s0.y, as[r]);
+                    as[r] = fma(static_cast<double>(w[r][p].z), s1.x, as[r]);
+                    as[r] = fma(static_cast<double>(w[r][p].w), s1.y, as[r]);
+                    ab[r] = fma(static_cast<double>(w[r][p].x), b0.x, ab[r]);
+                    ab[r] = fma(static_cast<double>(w[r][p].y), b0.y, ab[r]);
+                    ab[r] = fma(static_cast<double>(w[r][p].z), b1.x, ab[r]);
+                    ab[r] = fma(static_cast<double>(w[r][p].w), b1.y, ab[r]);
+                }
+            }
+        }
+    }
+}
+
+template <int RPW>
+__global__ __launch_bounds__(kThreads) void k_gamma_beta_multi(GemvBatch B) {
+    __shared__ double red[8 * RPW];
+    int li = 0;
+    for (int i = 1; i < B.n; ++i)
+        if (static_cast<int>(blockIdx.x) >= B.L[i].block0) li = i;          // uniform over the workgroup
+    const float *W = B.L[li].W;
+    const double *m = B.L[li].m;
+    float *gamma = B.L[li].gamma, *beta = B.L[li].beta;
+    const int Co = B.L[li].Co, K = B.L[li].K;
+    const int co0 = (static_cast<int>(blockIdx.x) - B.L[li].block0) * RPW;
+    double as[RPW], ab[RPW];
+    if (B.L[li].vec) gemv_rows_pre<RPW>(W, m, Co, K, co0, as, ab);
+    else gemv_rows<false, RPW>(W, m, Co, K, co0, as, ab);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        as[r] = block_sum(as[r], red + 8 * r);
+        ab[r] = block_sum(ab[r], red + 8 * r + 4);
+        if (threadIdx.x == 0 && co0 + r < Co) {
+            gamma[co0 + r] = static_cast<float>(as[r]);
+            beta[co0 + r] = static_cast<float>(ab[r]);
+        }
+    }
+}
+
+// The rank-2 update dW[co, :] (+)= dgamma[co] * m_scale + dbeta[co] * m_bias of several layers in one launch, the
+// accumulate form with all of a thread's loads of dW in flight before the first store.
+struct Rank2Layer {
+    const float *dg, *db;
+    const double *m;
+    float *dW;
+    int Co, K, block0, vec;
+};
+struct Rank2Batch {
+    Rank2Layer L[kGemvMaxLayers];
+    int n;
+};
+
+template <int RPW, bool ACC>
+__global__ __launch_bounds__(kThreads) void k_rank2_multi(Rank2Batch B) {
+    int li = 0;
+    for (int i = 1; i < B.n; ++i)
+        if (static_cast<int>(blockIdx.x) >= B.L[i].block0) li = i;
+    const double *s = B.L[li].m;
+    float *dW = B.L[li].dW;
+    const int Co = B.L[li].Co, K = B.L[li].K;
+    const int co0 = (static_cast<int>(blockIdx.x) - B.L[li].block0) * RPW;
+    float dg[RPW], db[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int co = min(co0 + r, Co - 1);
+        dg[r] = B.L[li].dg[co];
+        db[r] = B.L[li].db[co];
+    }
+    if (!B.L[li].vec) {
+        write_dw_rows<false, RPW, ACC>(dW, s, Co, K, co0, dg, db);
+        return;
+    }
+    const double2 *ss2 = reinterpret_cast<const double2 *>(s);
+    const double2 *sb2 = reinterpret_cast<const double2 *>(s + K);
+    const int K4 = K / 4;
+    for (int base = 0; base < K4; base += kGemvPre * kThreads) {
+        float4 w[RPW][kGemvPre];
+        if (ACC) {
+#pragma unroll
+            for (int p = 0; p < kGemvPre; ++p) {
+                const int q = base + p * kThreads + static_cast<int>(threadIdx.x);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+                    w[r][p] = (q < K4 && co0 + r < Co)
+                                  ? reinterpret_cast<const float4 *>(dW + static_cast<size_t>(co0 + r) * K)[q]
+                                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kGemvPre; ++p) {
+            const int q = base + p * kThreads + static_cast<int>(threadIdx.x);
+            if (q < K4) {
+                const double2 s0 = ss2[2 * q], s1 = ss2[2 * q + 1];
+                const double2 b0 = sb2[2 * q], b1 = sb2[2 * q + 1];
+                const float4 ms = make_float4(static_cast<float>(s0.x), static_cast<float>(s0.y),
+                                              static_cast<float>(s1.x), static_cast<float>(s1.y));
+                const float4 mb = make_float4(static_cast<float>(b0.x), static_cast<float>(b0.y),
+                                              static_cast<float>(b1.x), static_cast<float>(b1.y));
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    if (co0 + r >= Co) break;
+                    float4 o;                     // the same roundings as write_dw_rows: fmaf(dg, ms, db * mb) (+ dW)
+                    o.x = fmaf(dg[r], ms.x, db[r] * mb.x);
+                    o.y = fmaf(dg[r], ms.y, db[r] * mb.y);
+                    o.z = fmaf(dg[r], ms.z, db[r] * mb.z);
+                    o.w = fmaf(dg[r], ms.w, db[r] * mb.w);
+                    if (ACC) o = make_float4(w[r][p].x + o.x, w[r][p].y + o.y, w[r][p].z + o.z, w[r][p].w + o.w);
+                    reinterpret_cast<float4 *>(dW + static_cast<size_t>(co0 + r) * K)[q] = o;
+                }
+            }
+        }
+    }
 }
 
 // ============================================================================================
@@ -2364,40 +2531,80 @@ int deepipr_pooled_patch_mean(const float *keys, int nkeys, int B, int Ci, int H
 int deepipr_gamma_beta_fwd(const float *W, const double *s, int Co, int K, float *gamma, float *beta,
                            void *stream) {
     if (!W || !s || !gamma || !beta || Co <= 0 || K <= 0) return fail(DEEPIPR_EINVAL, "gamma_beta_fwd: bad argument");
+    const DeepiprGemvLayer one{W, s, gamma, beta, Co, K};
+    return deepipr_gamma_beta_fwd_multi(&one, 1, stream);
+}
+
+int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *stream) {
+    if (!layers || n <= 0 || n > kGemvMaxLayers)
+        return fail(DEEPIPR_EINVAL, "gamma_beta_fwd_multi: 1..%d layers per call", kGemvMaxLayers);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
-    const bool vec = K % 4 == 0 && aligned16(W) && aligned16(s);
-    if (Co >= 2 * kRowPairMinCo) {               // enough rows to fill the chip with two per workgroup
-        const dim3 grid((Co + 1) / 2);
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta<true, 2>), grid, dim3(kThreads), st, W, s, Co, K, gamma, beta);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta<false, 2>), grid, dim3(kThreads), st, W, s, Co, K, gamma, beta);
-    } else {
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta<true, 1>), dim3(Co), dim3(kThreads), st, W, s, Co, K, gamma, beta);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta<false, 1>), dim3(Co), dim3(kThreads), st, W, s, Co, K, gamma, beta);
+    long long rows = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const DeepiprGemvLayer &l = layers[i];
+        if (!l.W || !l.m || !l.gamma || !l.beta || l.Co <= 0 || l.K <= 0)
+            return fail(DEEPIPR_EINVAL, "gamma_beta_fwd_multi: bad layer %d", i);
+        rows += l.Co;
+        bytes += 4.0 * static_cast<double>(l.Co) * l.K;
     }
+    // two rows of W per workgroup share the pooled vectors (half the L2 -> CU traffic) once that still leaves >= 4
+    // workgroups per CU
+    const int cus = device_cu_count();
+    const int rpw = rows >= 8ll * (cus > 0 ? cus : 256) ? 2 : 1;
+    GemvBatch B{};
+    B.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const DeepiprGemvLayer &l = layers[i];
+        B.L[i] = GemvLayer{l.W, l.m, l.gamma, l.beta, l.Co, l.K, blocks,
+                           (l.K % 4 == 0 && aligned16(l.W) && aligned16(l.m)) ? 1 : 0};
+        blocks += (l.Co + rpw - 1) / rpw;
+    }
+    ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
+    prof.bytes = bytes;
+    if (rpw == 2) DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<2>), dim3(blocks), dim3(kThreads), st, B);
+    else DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<1>), dim3(blocks), dim3(kThreads), st, B);
     return check_launch("gamma_beta_fwd");
 }
 
-}  // extern "C"
-
-namespace {
-template <bool ACC>
-int launch_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double *s, int Co, int K, float *dW,
-                          hipStream_t st) {
-    ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
-    prof.bytes = (ACC ? 8.0 : 4.0) * static_cast<double>(Co) * K;
-    const bool vec = K % 4 == 0 && aligned16(dW) && aligned16(s);
-    if (Co >= 2 * kRowPairMinCo) {
-        const dim3 grid((Co + 1) / 2);
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 2, ACC>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 2, ACC>), grid, dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-    } else {
-        if (vec) DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<true, 1, ACC>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
-        else DEEPIPR_LAUNCH(prof, (k_gamma_beta_bwd<false, 1, ACC>), dim3(Co), dim3(kThreads), st, dgamma, dbeta, s, Co, K, dW);
+int deepipr_gamma_beta_bwd_multi(const DeepiprRank2Layer *layers, int n, int accumulate, void *stream) {
+    if (!layers || n <= 0 || n > kGemvMaxLayers)
+        return fail(DEEPIPR_EINVAL, "gamma_beta_bwd_multi: 1..%d layers per call", kGemvMaxLayers);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    long long rows = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const DeepiprRank2Layer &l = layers[i];
+        if (!l.dgamma || !l.dbeta || !l.m || !l.dW || l.Co <= 0 || l.K <= 0)
+            return fail(DEEPIPR_EINVAL, "gamma_beta_bwd_multi: bad layer %d", i);
+        rows += l.Co;
+        bytes += (accumulate ? 8.0 : 4.0) * static_cast<double>(l.Co) * l.K;
     }
-    return check_launch(ACC ? "gamma_beta_bwd_acc" : "gamma_beta_bwd");
+    const int cus = device_cu_count();
+    const int rpw = rows >= 8ll * (cus > 0 ? cus : 256) ? 2 : 1;
+    Rank2Batch B{};
+    B.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const DeepiprRank2Layer &l = layers[i];
+        B.L[i] = Rank2Layer{l.dgamma, l.dbeta, l.m, l.dW, l.Co, l.K, blocks,
+                            (l.K % 4 == 0 && aligned16(l.dW) && aligned16(l.m)) ? 1 : 0};
+        blocks += (l.Co + rpw - 1) / rpw;
+    }
+    ProfScope prof(DEEPIPR_K_GAMMA_BETA_BWD, st);
+    prof.bytes = bytes;
+    if (accumulate) {
+        if (rpw == 2) DEEPIPR_LAUNCH(prof, (k_rank2_multi<2, true>), dim3(blocks), dim3(kThreads), st, B);
+        else DEEPIPR_LAUNCH(prof, (k_rank2_multi<1, true>), dim3(blocks), dim3(kThreads), st, B);
+    } else {
+        if (rpw == 2) DEEPIPR_LAUNCH(prof, (k_rank2_multi<2, false>), dim3(blocks), dim3(kThreads), st, B);
+        else DEEPIPR_LAUNCH(prof, (k_rank2_multi<1, false>), dim3(blocks), dim3(kThreads), st, B);
+    }
+    return check_launch(accumulate ? "gamma_beta_bwd_acc" : "gamma_beta_bwd");
 }
-}  // namespace
+
+}  // extern "C"
 
 extern "C" {
 
@@ -2405,14 +2612,16 @@ int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double
                            float *dW, void *stream) {
     if (!dgamma || !dbeta || !s || !dW || Co <= 0 || K <= 0)
         return fail(DEEPIPR_EINVAL, "gamma_beta_bwd: bad argument");
-    return launch_gamma_beta_bwd<false>(dgamma, dbeta, s, Co, K, dW, static_cast<hipStream_t>(stream));
+    const DeepiprRank2Layer one{dgamma, dbeta, s, dW, Co, K};
+    return deepipr_gamma_beta_bwd_multi(&one, 1, 0, stream);
 }
 
 int deepipr_gamma_beta_bwd_acc(const float *dgamma, const float *dbeta, const double *s, int Co, int K,
                                float *dW, void *stream) {
     if (!dgamma || !dbeta || !s || !dW || Co <= 0 || K <= 0)
         return fail(DEEPIPR_EINVAL, "gamma_beta_bwd_acc: bad argument");
-    return launch_gamma_beta_bwd<true>(dgamma, dbeta, s, Co, K, dW, static_cast<hipStream_t>(stream));
+    const DeepiprRank2Layer one{dgamma, dbeta, s, dW, Co, K};
+    return deepipr_gamma_beta_bwd_multi(&one, 1, 1, stream);
 }
 
 size_t deepipr_gamma_beta_dkey_workspace_bytes(int Ci, int kh, int kw) {
@@ -2749,6 +2958,15 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
     if (plan_resident(N, C, HW, 16, have_sync != 0, &rp)) mask |= 1;
     if (plan_resident(N, C, HW, 8, have_sync != 0, &rp)) mask |= 2;
     return mask;
+}
+
+int deepipr_passport_bn_slices(int N, int C, int HW) {
+    if (bad_dims(N, C, HW)) return 1;
+    ResPlan rp;
+    int S = 1;
+    if (plan_resident(N, C, HW, 16, true, &rp) && rp.S > S) S = rp.S;
+    if (plan_resident(N, C, HW, 8, true, &rp) && rp.S > S) S = rp.S;
+    return S;
 }
 
 int deepipr_debug_tune(const char *key, int value) {

@@ -79,11 +79,14 @@ def replicate(model, device, bucket_mb=BUCKET_MB, static_graph=True):
     check_keys_materialised(model)
     broadcast_state(model, 0)
     from deepipr_amd import passport_ops
-    passport_ops.kernels.allow_sync = False   # DDP's bucket all-reduces share the device with backward
     ids = [device.index] if device.type == 'cuda' else None
-    return torch.nn.parallel.DistributedDataParallel(
+    ddp = torch.nn.parallel.DistributedDataParallel(
         model, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
         static_graph=static_graph)     # same parameters used every step: lets DDP skip per-iteration bookkeeping
+    # DDP's bucket all-reduces share the device with backward: the co-residency-dependent split-channel kernels are
+    # withheld for as long as the wrapper lives
+    passport_ops.kernels.withhold_sync(ddp)
+    return ddp
 
 
 def max_over_ranks(value, device):

@@ -70,21 +70,27 @@ class GraphedTrainStep:
                      for g in self.optimizer.param_groups)
 
     def _capture(self):
+        import contextlib
+
         from deepipr_amd import passport_ops
         optimizer = self.optimizer
         kernels = passport_ops.kernels
         optimizer.zero_grad(set_to_none=True)
-        hooks_off = getattr(optimizer, 'pause_hooks', None)
-        # Data-parallel replay with FlatSGD: every collective of a step is enqueued by optimizer.step() AFTER the
-        # replay and is waited for before the SGD kernel, i.e. before the next replay starts -- no RCCL kernel ever
-        # shares the device with the captured kernels, so the split-channel single-pass kernels (which need all
-        # their workgroups co-resident) can stay on inside the graph although FlatSGD switched them off for the
-        # eager, overlapped exchange.
-        exchange_after_replay = (not self.optimizer_in_graph) and hooks_off is not None
-        saved_allow = kernels.allow_sync
+        # Data-parallel replay with FlatSGD, un-staged form (experiments/staged.py is the default with several GPUs and
+        # overlaps the exchange): every collective of a step is enqueued by optimizer.step() AFTER the replay and is
+        # waited for before the SGD kernel, i.e. before the next replay starts -- no RCCL kernel ever shares the device
+        # with the captured kernels, so the split-channel single-pass kernels (which need all their workgroups
+        # co-resident) may stay on inside the graph.  sync_scope never overrides the USER's switch
+        # (DEEPIPR_ALLOW_SYNC=0 / kernels.set_user_sync(False)): after an exchange time-out the step is captured again
+        # without them.
+        exchange_after_replay = (not self.optimizer_in_graph) and hasattr(optimizer, 'set_mode')
+        scope = contextlib.nullcontext()
         if exchange_after_replay:
-            kernels.allow_sync = True
-        try:
+            optimizer.set_mode('single')               # rank-invariant: ONE all-reduce per step, no hooks
+            scope = kernels.sync_scope(True)
+        if hasattr(optimizer, 'prepare_in_place_capture'):
+            optimizer.prepare_in_place_capture()       # pinned chunk table of THIS capture, allocated outside it
+        with scope:
             kernels.prepare_stream(self.static_data.device, self.stream)
             self._device_hyper = hasattr(optimizer, 'sync_hyper')
             if self._device_hyper:
@@ -96,41 +102,14 @@ class GraphedTrainStep:
             # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
             mode = 'global' if self.optimizer_in_graph else 'thread_local'
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
-                if exchange_after_replay:
-                    with hooks_off():                      # no collective may be launched while capturing
-                        self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
-                else:
-                    self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
-        finally:
-            kernels.allow_sync = saved_allow
+                self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
         # the gradient tensors the replayed backward writes (graph-pool memory): `.grad` must point at them whenever the
         # optimiser runs OUTSIDE the graph, also after an eager step in between (a ragged last batch) re-bound it
         self._captured_grads = [(p, p.grad) for g in optimizer.param_groups for p in g['params']]
 
     def _dry_run(self, step_fn, model, optimizer):
-        base = model
-        while hasattr(base, 'module'):
-            base = base.module
-        saved = {k: v.clone() for k, v in base.state_dict().items()}
-        had_state = {id(p): ('momentum_buffer' in optimizer.state.get(p, {})) for g in optimizer.param_groups
-                     for p in g['params']}
-        mom = {id(p): optimizer.state[p]['momentum_buffer'].clone() for g in optimizer.param_groups
-               for p in g['params'] if had_state[id(p)] and optimizer.state[p]['momentum_buffer'] is not None}
-        flat_buf = optimizer.flat_buf.clone() if hasattr(optimizer, 'flat_buf') else None     # FlatSGD momentum
-        step_fn(model, optimizer, self.static_data, self.static_target)
-        with torch.no_grad():
-            if flat_buf is not None:
-                optimizer.flat_buf.copy_(flat_buf)
-            for k, v in base.state_dict().items():
-                v.copy_(saved[k])
-            for g in optimizer.param_groups:
-                for p in g['params']:
-                    buf = optimizer.state.get(p, {}).get('momentum_buffer')
-                    if buf is not None:
-                        buf.copy_(mom[id(p)]) if id(p) in mom else buf.zero_()
-        for m in base.modules():
-            if hasattr(m, 'invalidate_key_cache'):
-                m.invalidate_key_cache()                    # the in-place restore bumped the keys' version
+        from deepipr_amd.experiments.staged import dry_run
+        dry_run(lambda: step_fn(model, optimizer, self.static_data, self.static_target), model, optimizer)
 
     def __call__(self, data, target):
         if self._device_hyper:

@@ -69,17 +69,28 @@ def _check_exchange(device):
         passport_ops.kernels.check_exchange()
 
 
-def train_step_v1(model, optimizer, data, target):
-    """One batch: zero_grad, reset sign losses, forward, CE + sum of sign losses, backward, SGD step
-    (trainer.py:128-145).  Returns device scalars (loss, sign_loss, top-1 %), no host sync."""
-    optimizer.zero_grad(set_to_none=True)
+def forward_loss_v1(model, data, target):
+    """Forward half of the V1 step (trainer.py:131-142): -> (objective = CE + sum of sign losses, the step's device
+    scalars (loss, sign_loss, top-1 %)).  Separate from train_step_v1 so that a driver can run the backward pass
+    itself -- experiments/staged.py back-propagates stage by stage to overlap the gradient exchange."""
     reset_sign_losses(model)
     pred = model(data)
     loss, top1 = cross_entropy_top1(pred, target)          # F.cross_entropy + accuracy()[0], one fused launch on the GPU
     sign_loss = total_sign_loss(model, data.device)
-    (loss + sign_loss).backward()
+    return loss + sign_loss, (loss.detach(), sign_loss.detach(), top1)
+
+
+def train_step_v1(model, optimizer, data, target):
+    """One batch: zero_grad, reset sign losses, forward, CE + sum of sign losses, backward, SGD step
+    (trainer.py:128-145).  Returns device scalars (loss, sign_loss, top-1 %), no host sync."""
+    optimizer.zero_grad(set_to_none=True)
+    objective, out = forward_loss_v1(model, data, target)
+    objective.backward()
     optimizer.step()
-    return loss.detach(), sign_loss.detach(), top1
+    return out
+
+
+train_step_v1.forward_loss = forward_loss_v1
 
 
 class Tester(object):
@@ -113,24 +124,32 @@ class Tester(object):
 
 
 class StepRunner:
-    """Runs step_fn eagerly, or -- graph=True, single GPU, fixed batch shape -- from a hipGraph captured on the
-    first full batch (experiments/graph_step.py); ragged last batches fall back to the eager step."""
+    """Runs step_fn eagerly, or -- graph=True, fixed batch shape -- from hipGraphs captured on the first full batch;
+    ragged last batches fall back to the eager step.
+      one GPU      : the whole step, optimiser included, is one graph (experiments/graph_step.py);
+      data parallel: the staged form (experiments/staged.py) -- forward + backward as a few graphs cut at the gradient
+                     buckets' boundaries, each bucket's RCCL all-reduce launched between the replays, one fused SGD."""
 
     def __init__(self, step_fn, model, optimizer, graph=False):
         self.step_fn, self.model, self.optimizer = step_fn, model, optimizer
         self.graph = graph
-        # data parallel: capture forward+backward only, exchange gradients and step eagerly after each replay
-        self.opt_in_graph = not (torch.distributed.is_available() and torch.distributed.is_initialized())
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         self._graphed = None
         self._shape = None
+
+    def _build(self, data, target):
+        if self.distributed and hasattr(self.optimizer, 'configure_stages') and hasattr(self.step_fn, 'forward_loss'):
+            from deepipr_amd.experiments.staged import StagedStep
+            return StagedStep(self.step_fn, self.model, self.optimizer, data, target, graph=True, warmup=0)
+        from deepipr_amd.experiments.graph_step import GraphedTrainStep
+        return GraphedTrainStep(self.step_fn, self.model, self.optimizer, data, target, warmup=0,
+                                optimizer_in_graph=not self.distributed)
 
     def __call__(self, data, target):
         if not self.graph or not data.is_cuda:
             return self.step_fn(self.model, self.optimizer, data, target)
         if self._graphed is None:
-            from deepipr_amd.experiments.graph_step import GraphedTrainStep
-            self._graphed = GraphedTrainStep(self.step_fn, self.model, self.optimizer, data, target, warmup=0,
-                                             optimizer_in_graph=self.opt_in_graph)
+            self._graphed = self._build(data, target)
             self._shape = (tuple(data.shape), tuple(target.shape))
             return self._graphed(data, target)          # capture does not execute: replay the first batch
         if (tuple(data.shape), tuple(target.shape)) != self._shape:

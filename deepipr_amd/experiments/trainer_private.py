@@ -36,18 +36,28 @@ def _unwrap(model):
     return model.model if isinstance(model, DualBranch) else model
 
 
-def train_step_v23(dual, optimizer, data, target):
-    """-> device scalars (loss, sign_loss, public top-1 %, private top-1 %)."""
-    optimizer.zero_grad(set_to_none=True)
+def forward_loss_v23(dual, data, target):
+    """Forward half of the V2 / V3 step (trainer_private.py:159-171): both branches, -> (objective, device scalars
+    (loss, sign_loss, public top-1 %, private top-1 %)); see trainer.forward_loss_v1."""
     reset_sign_losses(dual)
     pred_public, pred_private = dual(data)
     loss_public, top1_public = cross_entropy_top1(pred_public, target)
     loss_private, top1_private = cross_entropy_top1(pred_private, target)
     loss = loss_public + loss_private
     sign_loss = total_sign_loss(dual, data.device)
-    (loss + sign_loss).backward()
+    return loss + sign_loss, (loss.detach(), sign_loss.detach(), top1_public, top1_private)
+
+
+def train_step_v23(dual, optimizer, data, target):
+    """-> device scalars (loss, sign_loss, public top-1 %, private top-1 %)."""
+    optimizer.zero_grad(set_to_none=True)
+    objective, out = forward_loss_v23(dual, data, target)
+    objective.backward()
     optimizer.step()
-    return loss.detach(), sign_loss.detach(), top1_public, top1_private
+    return out
+
+
+train_step_v23.forward_loss = forward_loss_v23
 
 
 class TesterPrivate(object):

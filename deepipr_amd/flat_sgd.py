@@ -39,8 +39,17 @@ class FlatSGD(torch.optim.Optimizer):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # DEEPIPR_FORCE_DDP=1: run the bucketed exchange even in a world of one (single-GPU rehearsal of the N>1 path)
         self.comm = self.world > 1 or (dist.is_initialized() and os.environ.get('DEEPIPR_FORCE_DDP') == '1')
+        # How the gradient exchange is driven -- chosen by whoever drives the step, identical on every rank (never from
+        # which hooks happened to fire locally):
+        #   'hooks'  eager backward: buckets are launched from post-accumulate-grad hooks, overlapped with backward;
+        #   'single' the backward was a replayed hipGraph without stages: ONE pack + ONE all-reduce in step();
+        #   'staged' experiments/staged.py runs the backward stage by stage and calls exchange_stage() in between.
+        self._mode = 'hooks'
         if self.comm:
-            P.kernels.allow_sync = False      # collectives share the device: no co-residency-dependent kernels
+            # collectives launched from hooks share the device with backward kernels: the co-residency-dependent
+            # split-channel kernels are withheld while this optimiser drives an overlapped exchange (released again
+            # by set_mode('single') / configure_stages(), and when the optimiser is garbage-collected)
+            P.kernels.withhold_sync(self)
         plist = self.param_groups[0]['params']
         if len(self.param_groups) != 1:
             raise ValueError('FlatSGD keeps one parameter group (one lr / momentum / weight decay)')
@@ -66,13 +75,14 @@ class FlatSGD(torch.optim.Optimizer):
         self._hyper_host = None
         # chunk table of the in-place update (_step_in_place): pinned host rows + their device copy, allocated here
         # because nothing may be allocated on the host side while a stream is being captured
-        self._tab_host = self._tab_dev = None
+        self._tables = []                 # one (pinned host rows, device copy) pair PER capture, kept alive
+        self._table_ready = None          # the pair prepare_in_place_capture() made for the next capture
         self.in_place_captures = 0
+        self._tab_rows = 0
         if dev.type == 'cuda' and not self.comm and hasattr(P.kernels, 'sgd_chunk'):
             chunk = P.kernels.sgd_chunk()
-            nrows = sum((p.numel() + chunk - 1) // chunk for p in plist)
-            self._tab_host = torch.empty((nrows, 3), dtype=torch.int64).pin_memory()
-            self._tab_dev = torch.empty((nrows, 3), dtype=torch.int64, device=dev)
+            self._tab_rows = sum((p.numel() + chunk - 1) // chunk for p in plist)
+            self.prepare_in_place_capture()
         with torch.no_grad():
             for p, off in zip(order, offsets):
                 view = self.flat_param[off:off + p.numel()].view_as(p)
@@ -103,6 +113,8 @@ class FlatSGD(torch.optim.Optimizer):
         self._works = []
         self._hooks = []
         self._paused = False
+        self._side = None                 # side stream of the staged exchange (pack + all-reduce off the main stream)
+        self.exposed_events = None        # staged mode, optional: [(start, stop)] events around the exposed exchange
         if self.comm and len(self._buckets) > 1:
             for p, _ in self._slots[:self._buckets[-1][0]]:          # every bucket but the last
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -166,8 +178,86 @@ class FlatSGD(torch.optim.Optimizer):
                 return False
         return _Pause()
 
+    def set_mode(self, mode):
+        """'hooks' | 'single' | 'staged' (see __init__).  Must be called with the same value on every rank."""
+        if mode not in ('hooks', 'single', 'staged'):
+            raise ValueError(mode)
+        if mode != 'hooks':
+            for h in self._hooks:
+                h.remove()
+            self._hooks = []
+            P.kernels.release_sync(self)       # no collective is launched from inside a backward pass any more
+        elif self.comm and not self._hooks:
+            raise RuntimeError('FlatSGD: the gradient hooks were removed; build a new optimiser for the hooks mode')
+        self._mode = mode
+
+    def configure_stages(self, stage_params):
+        """Buckets = the parameter lists of the staged backward (experiments/staged.py), in stage order.  Every stage
+        must be a contiguous run of the flat layout (reverse registration order) and together they must cover it;
+        -> True and mode 'staged', or False (layout does not fit: buckets and mode stay as they were)."""
+        index = {id(p): i for i, (p, _) in enumerate(self._slots)}
+        bounds, pos = [], 0
+        for params in stage_params:
+            ids = sorted(index[id(p)] for p in params if id(p) in index)
+            if not ids:
+                continue
+            if ids[0] != pos or ids != list(range(ids[0], ids[-1] + 1)):
+                return False
+            pos = ids[-1] + 1
+            bounds.append((ids[0], pos))
+        if pos != len(self._slots):
+            return False
+        self._buckets = bounds
+        self._bucket_of = {id(self._slots[i][0]): b for b, (lo, hi) in enumerate(bounds) for i in range(lo, hi)}
+        self._pending = [hi - lo for lo, hi in bounds]
+        self._launched = [False] * len(bounds)
+        self.set_mode('staged')
+        return True
+
+    def bucket_bytes(self):
+        return [4 * (self._range(b)[1] - self._range(b)[0]) for b in range(len(self._buckets))]
+
+    def exchange_stages(self, lo, hi, after=None, overlap=True):
+        """Staged mode: pack the gradients of buckets lo..hi-1 into the flat gradient buffer and all-reduce that
+        range as ONE message.  overlap=True: on a side stream that first waits for the event `after` (recorded on the
+        main stream behind the stage that finished these gradients), so the main stream can go on with the next
+        stage; the all-reduce is waited for in step() (or by wait_exchange()).  overlap=False: on the current stream."""
+        if lo >= hi:
+            return
+        cuda = self.flat_grad.is_cuda
+        start = self._slots[self._buckets[lo][0]][1]
+        end = self._range(hi - 1)[1]
+
+        def go():
+            self._pack_slots(self._buckets[lo][0], self._buckets[hi - 1][1])
+            if self.comm:
+                w = dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._works.append(w)
+        if cuda and overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.flat_grad.device)
+            if after is not None:
+                self._side.wait_event(after)
+            else:
+                self._side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
+            with torch.cuda.stream(self._side):
+                go()
+        else:
+            go()
+        for b in range(lo, hi):
+            self._launched[b] = True
+
+    def wait_exchange(self):
+        """Make the current stream wait for every all-reduce launched so far (the packs run on the same side stream in
+        front of them).  NCCL/RCCL: a stream-side wait, the host does not block."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._side is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+
     def _on_grad(self, param):
-        if self._paused:
+        if self._paused or self._mode != 'hooks':
             return
         b = self._bucket_of[id(param)]
         self._pending[b] -= 1
@@ -201,14 +291,30 @@ class FlatSGD(torch.optim.Optimizer):
         missing = self._missing_grads()
         if capturing and not self.comm and not missing and self._step_in_place():
             return loss                                   # gradients read where autograd left them: no packing pass
-        if not any(self._launched):
-            # No bucket left from a gradient hook -- one GPU, or the backward was a replayed hipGraph (hooks paused
-            # at capture, nothing to overlap with any more): ONE pack and ONE all-reduce of the whole buffer.  xGMI
-            # is point-to-point and per-link bound, so one 44.7 MB ring pass beats four of 19 / 15 / 8.5 / 2.7 MB.
+        # The collective layout follows the MODE, which the driver of the step sets identically on every rank -- never
+        # rank-local state such as which hooks happened to fire (ranks issuing different sets of collectives hang).
+        if self._mode == 'staged':
+            timed = self.exposed_events is not None and self.flat_grad.is_cuda and not capturing
+            if timed:                                     # what is NOT hidden behind backward: from here to the update
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            rest = [b for b in range(len(self._buckets)) if not self._launched[b]]
+            if rest:                                      # stages nobody exchanged yet: one message, current stream
+                if rest != list(range(rest[0], len(self._buckets))):
+                    raise RuntimeError('FlatSGD: staged exchange must proceed in stage order')
+                self.exchange_stages(rest[0], len(self._buckets), overlap=False)
+            self.wait_exchange()
+            if timed:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                self.exposed_events.append((ev0, ev1))
+        elif self._mode == 'single' or not self.comm or len(self._buckets) == 1:
+            # One GPU, or the backward was a replayed hipGraph without stages (nothing to overlap with): ONE pack and
+            # ONE all-reduce of the whole buffer.
             self._pack_slots(0, len(self._slots))
             if self.comm:
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        else:
+        else:                                             # 'hooks': always the bucket layout
             for b in range(len(self._buckets)):
                 if not self._launched[b]:
                     self._launch(b, async_op=False)
@@ -239,6 +345,15 @@ class FlatSGD(torch.optim.Optimizer):
         self._pending = [hi - lo for lo, hi in self._buckets]
         return loss
 
+    def prepare_in_place_capture(self):
+        """Allocate the chunk table of the NEXT captured in-place update (pinned host rows + device copy).  Nothing may
+        be allocated on the host while a stream is being captured, so whoever captures calls this first
+        (GraphedTrainStep does); without a prepared table the captured step takes the packed path."""
+        if self._tab_rows and self._table_ready is None:
+            dev = self.flat_param.device
+            self._table_ready = (torch.empty((self._tab_rows, 3), dtype=torch.int64).pin_memory(),
+                                 torch.empty((self._tab_rows, 3), dtype=torch.int64, device=dev))
+
     def _step_in_place(self):
         """One GPU, step being captured into a hipGraph: the gradient tensors' addresses are the ones every replay will
         use, so the update kernel can read them in place through a table of {address, flat offset, count} chunks built
@@ -254,11 +369,16 @@ class FlatSGD(torch.optim.Optimizer):
             for lo in range(0, n, chunk):
                 rows.append((base + 4 * lo, off + lo, min(chunk, n - lo)))
             total += n
-        if self._tab_host is None or len(rows) > self._tab_host.shape[0]:
-            return False                                  # (buffers are sized at construction, never inside a capture)
-        self._tab_host[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
-        table = self._tab_dev[:len(rows)]
-        table.copy_(self._tab_host[:len(rows)], non_blocking=True)   # a memcpy node: replays re-read the pinned rows
+        if self._table_ready is None or len(rows) > self._table_ready[0].shape[0]:
+            return False                                  # (tables are allocated outside captures: prepare_in_place_capture)
+        # every capture gets its OWN pinned rows + device copy: the captured memcpy node re-reads the pinned rows on
+        # every replay, so a later capture (another batch shape, a re-capture) must not overwrite an earlier one's
+        tab_host, tab_dev = self._table_ready
+        self._table_ready = None
+        self._tables.append((tab_host, tab_dev))
+        tab_host[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
+        table = tab_dev[:len(rows)]
+        table.copy_(tab_host[:len(rows)], non_blocking=True)         # a memcpy node: replays re-read the pinned rows
         P.kernels.sgd_momentum_step_multi(self.flat_param, self.flat_buf, table, total, self._hyper)
         self.in_place_captures += 1
         self._works = []

@@ -8,6 +8,7 @@ three-layer dropout classifier.  `features` indices 0,2,4,5,6 are the conv layer
 import torch
 import torch.nn as nn
 
+from deepipr_amd import cuts
 from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 
@@ -54,7 +55,14 @@ class AlexNetPassport(nn.Module):
                 if y is not None:
                     y = theirs(y)
 
+    def backward_stages(self):
+        """Stages of the staged data-parallel backward (experiments/staged.py), last layers first: the classifier and
+        features 5-6 (the larger half of the CIFAR net's parameters), then everything before."""
+        return [('features.5', list(self.features[5:]) + [self.classifier]), (None, list(self.features[:5]))]
+
     def forward(self, x, force_passport=False, ind=0):
-        for m in self.features:
+        for i, m in enumerate(self.features):
+            if i == 5:
+                x = cuts.mark('features.5', x)
             x = run_layer(m, x, force_passport, ind)
         return self.classifier(x.view(x.size(0), -1))

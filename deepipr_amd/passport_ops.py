@@ -115,6 +115,45 @@ class HipKernels:
                                                             _p(dw), _stream(dev)), 'gamma_beta_bwd_acc')
         return dw
 
+    def gamma_beta_fwd_multi(self, weights, ms, out=None):
+        """gamma / beta of several passport layers in ONE launch (deepipr_gamma_beta_fwd_multi): weights[i] [Co_i, ...],
+        ms[i] [2, K_i] float64.  -> [(gamma_i, beta_i)], views of one [2 * sum(Co)] allocation (`out` to reuse one)."""
+        dev = _chk(*weights, *ms)
+        n = len(weights)
+        if not 0 < n <= _lib.GEMV_MAX_LAYERS or len(ms) != n:
+            raise RuntimeError('gamma_beta_fwd_multi: 1..%d layers per call' % _lib.GEMV_MAX_LAYERS)
+        cos = [w.shape[0] for w in weights]
+        total = sum(cos)
+        if out is None:
+            out = torch.empty(2 * total, dtype=torch.float32, device=dev)
+        arr = (_lib.GemvLayer * n)()
+        res, off, base = [], 0, out.data_ptr()
+        for i, (w, m) in enumerate(zip(weights, ms)):
+            co = cos[i]
+            arr[i] = _lib.GemvLayer(w.data_ptr(), m.data_ptr(), base + 4 * off, base + 4 * (off + co), co,
+                                    w.numel() // co)
+            res.append((out[off:off + co], out[off + co:off + 2 * co]))
+            off += 2 * co
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_gamma_beta_fwd_multi(arr, n, _stream(dev)), 'gamma_beta_fwd_multi')
+        return res
+
+    def gamma_beta_bwd_multi(self, dgammas, dbetas, ms, dws, accumulate):
+        """dW_i (+)= dgamma_i (x) m_scale_i + dbeta_i (x) m_bias_i for several layers in one launch."""
+        dev = _chk(*dgammas, *dbetas, *ms, *dws)
+        n = len(dws)
+        if not 0 < n <= _lib.GEMV_MAX_LAYERS:
+            raise RuntimeError('gamma_beta_bwd_multi: 1..%d layers per call' % _lib.GEMV_MAX_LAYERS)
+        arr = (_lib.Rank2Layer * n)()
+        for i in range(n):
+            co = dws[i].shape[0]
+            arr[i] = _lib.Rank2Layer(dgammas[i].data_ptr(), dbetas[i].data_ptr(), ms[i].data_ptr(), dws[i].data_ptr(),
+                                     co, dws[i].numel() // co)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_gamma_beta_bwd_multi(arr, n, int(bool(accumulate)), _stream(dev)),
+                       'gamma_beta_bwd_multi')
+        return dws
+
     def gamma_beta_dkey(self, dgamma, dbeta, weight, key_shape, stride, pad):
         dev = _chk(dgamma, dbeta, weight)
         co, ci, kh, kw = weight.shape
@@ -233,11 +272,68 @@ class HipKernels:
         return buf.data_ptr()
 
     # In-launch exchange words of the register-resident kernels (include/deepipr_hip.h, DEEPIPR_SYNC_WORDS): one
-    # zero-initialised buffer per (device, stream), owned by the library afterwards.  `allow_sync` is cleared by
-    # whoever runs kernels on a second stream of the same device (FlatSGD / DDP gradient exchange): the split-channel
-    # form needs every workgroup co-resident, which a concurrent collective can delay.
+    # zero-initialised buffer per (device, stream), owned by the library afterwards.
+    #
+    # Who may take the split-channel form (its workgroups must all be co-resident, which a concurrent kernel of
+    # another stream -- an RCCL collective -- can delay):
+    #   sync_user      the USER's switch (DEEPIPR_ALLOW_SYNC=0 or set_user_sync(False)): honoured on every path,
+    #                  graph capture included; what check_exchange() tells the user to clear after a time-out;
+    #   withheld       owners that currently launch collectives from inside a backward pass (FlatSGD in hooks mode,
+    #                  DDP): while any is alive, eager calls do not get the exchange words;
+    #   sync_scope()   an explicit decision for a region by a driver that KNOWS the region's concurrency (the staged
+    #                  stepper: a stage that never overlaps a collective may use the split form although the optimiser
+    #                  exchanges gradients) -- it overrides `withheld`, never the user's switch.
     _sync = {}
-    allow_sync = True
+    sync_user = os.environ.get('DEEPIPR_ALLOW_SYNC', '1') != '0'
+    _sync_withheld = None
+    _sync_scoped = None
+    sync_launches = 0                  # calls that were handed exchange words for a split-channel plan (S > 1)
+
+    @property
+    def allow_sync(self):
+        if not self.sync_user:
+            return False
+        if self._sync_scoped is not None:
+            return self._sync_scoped
+        return not (self._sync_withheld is not None and len(self._sync_withheld))
+
+    def set_user_sync(self, on):
+        self.sync_user = bool(on)
+
+    def withhold_sync(self, owner):
+        import weakref
+        if self._sync_withheld is None:
+            self._sync_withheld = weakref.WeakSet()
+        self._sync_withheld.add(owner)
+
+    def release_sync(self, owner):
+        if self._sync_withheld is not None:
+            self._sync_withheld.discard(owner)
+
+    def sync_scope(self, allowed):
+        """Context manager: inside, allow_sync == (allowed and the user's switch), whatever owners withhold it."""
+        k = self
+
+        class _Scope:
+            def __enter__(self):
+                self.prev = k._sync_scoped
+                k._sync_scoped = bool(allowed)
+
+            def __exit__(self, *exc):
+                k._sync_scoped = self.prev
+                return False
+        return _Scope()
+
+    _slices = {}
+
+    def bn_slices(self, n, c, hw):
+        """Workgroups per channel of the single-pass BatchNorm kernels for this shape when exchange words are given
+        (1 = no in-launch exchange)."""
+        key = (n, c, hw)
+        v = self._slices.get(key)
+        if v is None:
+            v = self._slices[key] = _lib.lib().deepipr_passport_bn_slices(n, c, hw)
+        return v
 
     def _sync_words(self, dev, stream):
         if not self.allow_sync:
@@ -272,15 +368,16 @@ class HipKernels:
 
     def check_exchange(self):
         """Raise if an in-launch partial-sum exchange of the single-pass norm kernels ever timed out (its outputs were
-        poisoned with NaN).  The words are re-armed so that training can be restarted, e.g. with allow_sync=False."""
+        poisoned with NaN).  The words are re-armed so that training can be restarted, e.g. with set_user_sync(False)."""
         n = self.sync_timeouts()
         if n:
             self.reset_sync_words()
             raise RuntimeError(
                 'deepipr_amd: %d exchange buffer(s) report an expired in-kernel wait of the single-pass norm kernels '
                 '(their workgroups were not co-resident: is another process or stream using this GPU?). The affected '
-                'outputs were poisoned with NaN. Set passport_ops.kernels.allow_sync = False to use the three-launch '
-                'form for the split-channel layers.' % n)
+                'outputs were poisoned with NaN. Set DEEPIPR_ALLOW_SYNC=0 (or passport_ops.kernels.set_user_sync(False)) '
+                'to use the three-launch form for the split-channel layers; a captured step must be captured again '
+                'after that.' % n)
 
     def reset_sync_words(self):
         for buf in self._sync.values():
@@ -318,13 +415,16 @@ class HipKernels:
         if b is not None:
             bits = torch.empty(c, dtype=torch.int8, device=dev)
         ws = self._scratch(dev, st, self._bn_ws_bytes(n, c, hw)) if training else None
+        sync = self._sync_words(dev, st) if training else None
+        if sync is not None and self.bn_slices(n, c, hw) > 1:
+            self.sync_launches += 1
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_fwd(
                 x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
                 _p(running_mean), _p(running_var), _p(nbt), momentum, eps, int(training), n, c, hw, k, int(relu),
                 y.data_ptr(), base, p_gamma if weight is not None else None, p_beta if weight is not None else None,
                 p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), _p(residual),
-                ws, self._sync_words(dev, st) if training else None, st), 'passport_bn_fwd')
+                ws, sync, st), 'passport_bn_fwd')
         table = small[:8 * c].view(c, 8)
         gamma = beta = loss = acc = None
         if weight is not None:
@@ -349,12 +449,15 @@ class HipKernels:
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         pg = dgb.data_ptr()
         dres = torch.empty_like(x) if tail_out is not None else None
+        sync = self._sync_words(dev, st)
+        if sync is not None and self.bn_slices(n, c, hw) > 1:
+            self.sync_launches += 1
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_bwd(
                 dy.data_ptr(), x.data_ptr(), table.data_ptr(), _p(m), _p(b), alpha, margin, l2, _p(dloss),
                 _p(dgamma_extra), _p(dbeta_extra), int(training), n, c, hw,
                 (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c,
-                scratch + nws, scratch, self._sync_words(dev, st), _p(dy2), _p(tail_out), _p(dres), st),
+                scratch + nws, scratch, sync, _p(dy2), _p(tail_out), _p(dres), st),
                 'passport_bn_bwd')
         if tail_out is not None:
             return dx, dw, dgb[0], dgb[1], dres

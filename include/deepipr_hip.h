@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 4
+#define DEEPIPR_ABI_VERSION 5
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -99,6 +99,29 @@ int deepipr_gamma_beta_bwd(const float *dgamma, const float *dbeta, const double
  * 8 B per weight in one launch instead of a fresh 4 B write plus autograd's 12 B add kernel. */
 int deepipr_gamma_beta_bwd_acc(const float *dgamma, const float *dbeta, const double *m,
                                int Co, int K, float *dW, void *stream);
+
+/* The same three operations for SEVERAL layers in ONE launch each (a net's passport layers: ResNet18's five layer4
+ * weights are 33.6 MB, and one launch over all of them streams W at the bandwidth a single 9.4 MB launch cannot
+ * reach -- round 2 measured 0.17 of the HBM roofline per layer, latency-bound).  `layers` is a HOST array of n <=
+ * DEEPIPR_GEMV_MAX_LAYERS descriptors of device pointers; it is read during the call only (the descriptors travel in
+ * the kernel arguments).  The single-layer entry points above are the n = 1 case of these.
+ * replaces: the get_scale() / get_bias() passport convs of every passport layer of a forward,
+ *           models/layers/passportconv2d.py:148-152,169-173, and their backward. */
+#define DEEPIPR_GEMV_MAX_LAYERS 16
+typedef struct DeepiprGemvLayer {
+    const float *W;          /* [Co][K] */
+    const double *m;         /* [2][K] pooled patches, scale key first */
+    float *gamma, *beta;     /* [Co] out */
+    int Co, K;
+} DeepiprGemvLayer;
+typedef struct DeepiprRank2Layer {
+    const float *dgamma, *dbeta;   /* [Co] */
+    const double *m;               /* [2][K] */
+    float *dW;                     /* [Co][K]; accumulate != 0: holds the data convolution's wgrad and is added to */
+    int Co, K;
+} DeepiprRank2Layer;
+int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *stream);
+int deepipr_gamma_beta_bwd_multi(const DeepiprRank2Layer *layers, int n, int accumulate, void *stream);
 
 /* Gradient w.r.t. the passport tensors themselves (keys made nn.Parameters by
  * passport_attack_3.py:232-243).  dkeys[j][b][ci][ih][iw] = sum over patches covering (ih,iw) of
@@ -225,6 +248,11 @@ int deepipr_debug_tune(const char *key, int value);
  * 8 * 8 bytes per workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */
 int deepipr_debug_trace(unsigned long long *device_buffer);
 int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
+/* Workgroups per channel the single-pass kernels would use for this shape when exchange words are passed (the larger
+ * of forward and backward; 1 = no in-launch exchange, also when the shape is not single-pass).  Host-side planning
+ * only: lets a driver that overlaps collectives with compute know WHICH layer calls depend on co-residency
+ * (deepipr_amd/experiments/staged.py keeps collectives away from exactly those stages). */
+int deepipr_passport_bn_slices(int N, int C, int HW);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
                             const float *beta_in, const float *b, float alpha, float margin, float l2,

@@ -88,6 +88,20 @@ class OracleKernels:
 
     # ---- BatchNorm-fused entry points: stock ATen batch_norm on the host as the checker ----
     allow_sync = True
+    sync_launches = 0
+
+    def withhold_sync(self, owner):
+        self.allow_sync = False
+
+    def release_sync(self, owner):
+        self.allow_sync = True
+
+    def set_user_sync(self, on):
+        self.allow_sync = bool(on)
+
+    def sync_scope(self, allowed):
+        import contextlib
+        return contextlib.nullcontext()
 
     def bn_resident(self, n, c, hw):
         return 3                      # the host logic is exercised as if every shape took the single-pass form

@@ -33,3 +33,19 @@ def test_pmc_traffic_is_quoted_only_for_the_same_launch_mix():
 def test_host_cores_is_positive_and_bounded():
     bench = _bench()
     assert 1 <= bench.host_cores() <= 32
+
+
+def test_bench_self_launches_n_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself (the driver runs
+    that command verbatim on a multi-GPU node).  --dry-run --backend gloo exercises exactly that plumbing without a
+    GPU: torch.distributed.run re-execution, rendezvous on 127.0.0.1, barrier, one JSON line from rank 0."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--backend', 'gloo'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['dry_run'] is True and rec['value'] is None

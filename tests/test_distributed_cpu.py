@@ -77,7 +77,7 @@ def _worker(rank, world, port, private, out_dir, flat=False):
         wrapped = D.replicate(DualBranch(model) if private else model, dev)
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
         opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
-    # with a gradient exchange sharing the device, the co-residency-dependent single-pass kernels are switched off
+    # with a gradient exchange launched from inside backward, the co-residency-dependent single-pass kernels are withheld
     assert passport_ops.kernels.allow_sync is False
     x, y = _batch()
     lo, hi = rank * 4, rank * 4 + 4
@@ -92,15 +92,39 @@ def _worker(rank, world, port, private, out_dir, flat=False):
             calls.append(t.numel())
             return real_all_reduce(t, *a, **k)
 
+        opt.set_mode('single')                    # what GraphedTrainStep._capture does: rank-invariant, no hooks
+        assert passport_ops.kernels.allow_sync is True      # ... and nothing overlaps the captured kernels any more
+
         def step(wrapped, opt, xs, ys):
-            with opt.pause_hooks():
-                out = inner(wrapped, _NoStep(opt), xs, ys)
+            out = inner(wrapped, _NoStep(opt), xs, ys)
             dist.all_reduce = counted
             try:
                 opt.step()
             finally:
                 dist.all_reduce = real_all_reduce
             assert calls == [opt.flat_grad.numel()], calls
+            calls.clear()
+            return out
+    if flat == 'staged':
+        # experiments/staged.py, eager form: backward stage by stage, stage k's bucket all-reduced while stage k + 1
+        # back-propagates, the last one in optimizer.step() -- the collectives' order and sizes follow the stage plan
+        from deepipr_amd.experiments.staged import StagedStep
+        calls, real_all_reduce = [], dist.all_reduce
+
+        def counted(t, *a, **k):
+            calls.append(t.numel())
+            return real_all_reduce(t, *a, **k)
+        staged = StagedStep(step, wrapped, opt, x[lo:hi], y[lo:hi], graph=False, warmup=0)
+        assert opt._mode == 'staged' and len(staged.stages) == 2 and [s.cut for s in staged.stages] == ['features.5', None]
+        assert not [k for k, v in model.state_dict().items() if not torch.equal(v, state0[k])]   # warmup=0: a dry run
+
+        def step(wrapped, opt, xs, ys):
+            dist.all_reduce = counted
+            try:
+                out = staged(xs, ys)
+            finally:
+                dist.all_reduce = real_all_reduce
+            assert len(calls) == 2 and sum(calls) == opt.flat_grad.numel(), calls
             calls.clear()
             return out
     out = step(wrapped, opt, x[lo:hi], y[lo:hi])
@@ -112,7 +136,7 @@ def _worker(rank, world, port, private, out_dir, flat=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('flat', [False, True, 'replay'])
+@pytest.mark.parametrize('flat', [False, True, 'replay', 'staged'])
 @pytest.mark.parametrize('private', [False, True])
 def test_two_rank_step_equals_single_process_step(private, flat, tmp_path, monkeypatch):
     port = _free_port()

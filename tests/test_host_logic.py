@@ -514,3 +514,54 @@ def test_conv_inside_node_with_frozen_weight_and_input(cpu_kernels):
     y = blk(x)
     (y.sum() + blk.sign_loss.loss).backward()
     assert blk.weight.grad is None and blk.key.grad is not None and torch.isfinite(blk.key.grad).all()
+
+
+@pytest.mark.parametrize('private', [False, True])
+def test_staged_backward_equals_one_backward_pass(private, cpu_kernels):
+    """experiments/staged.py: the backward cut into stages at the model's named activations (torch.autograd.grad on
+    detached cut leaves, the objective kept as a root) must give EXACTLY the gradients and the step of one
+    loss.backward().  ResNet18 with passports -- hence sign losses -- in layer3 AND layer4: a sign loss of a layer in
+    a later stage reaches its layer only through the objective root, not through a cut; the residual blocks hand
+    their outputs out as two handles, so every cut is a pair; V2 marks every cut twice (public + private forward)."""
+    from deepipr_amd.experiments.staged import StagedStep
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.flat_sgd import FlatSGD
+    from deepipr_amd.models.resnet_passport import ResNet18Passport
+    from deepipr_amd.models.resnet_passport_private import ResNet18Private
+    from oracle.cases import resnet18_config
+    torch.set_num_threads(8)
+    cfg = resnet18_config()
+    cfg['layer3'] = {b: {k: True for k in v} for b, v in cfg['layer3'].items()}
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': 0.1})
+
+    def make():
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = (ResNet18Private if private else ResNet18Passport)(num_classes=10, passport_kwargs=kw)
+        net.train()
+        with torch.no_grad():
+            net(torch.randn(2, 3, 32, 32))
+        return net
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)
+    step = train_step_v23 if private else train_step_v1
+    a, b = make(), make()
+    wa, wb = (DualBranch(a), DualBranch(b)) if private else (a, b)
+    oa = FlatSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)     # the same update arithmetic on both sides
+    ob = FlatSGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    staged = StagedStep(step, wb, ob, x, y, graph=False, warmup=0)
+    assert [s.cut for s in staged.stages] == ['layer4.1', 'layer4.0', 'layer3.0', None] and ob._mode == 'staged'
+    assert sum(len(s.params) for s in staged.stages) == len(list(b.parameters()))
+    for it in range(2):
+        out_a = step(wa, oa, x, y)
+        grads_a = {k: p.grad.clone() for k, p in a.named_parameters()}
+        out_b = staged(x, y)
+        for k, p in b.named_parameters():
+            assert torch.equal(p.grad, grads_a[k]), (it, k, float((p.grad - grads_a[k]).abs().max()))
+        for u, v in zip(out_a, out_b):
+            assert torch.equal(u, v)
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(u, v), k

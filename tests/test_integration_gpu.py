@@ -1,7 +1,5 @@
-"""Runs INTEGRATION.md section B's reference-side ctypes stub on the GPU, as a maintainer of the reference would use it.
-
-Not collected by pytest (no test_ prefix): written at the end of round 2 without GPU time left to validate it -- run it
-once (`python tests/triage/integration_stub_gpu.py`, expect "stub ok"), then move it into tests/test_parity_gpu.py.
+"""INTEGRATION.md section B's reference-side ctypes stub, executed on the GPU as a maintainer of the reference would
+use it (first run on hardware in round 3: profiles/r03_integration_stub.log).
 
 What it does: extracts the stub's code block from INTEGRATION.md, points it at the in-tree library and drives
 `PassportAffine` + `pooled` forward and backward on a stride-2 3x3 block; the same inputs go through the product's
@@ -11,12 +9,12 @@ models/losses/sign_loss.py:27,53 in float64 (1e-5 of scale).
 """
 import os
 import re
-import sys
 
+import pytest
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
 
 
 def stub_namespace():
@@ -30,7 +28,8 @@ def stub_namespace():
     return ns
 
 
-def main():
+def test_reference_side_stub_of_integration_md_runs_on_the_gpu():
+    """The code block is EXTRACTED from INTEGRATION.md, so the document cannot drift from what is tested."""
     from deepipr_amd import passport_ops
     K = passport_ops.kernels
     ns = stub_namespace()
@@ -83,8 +82,3 @@ def main():
     close('dW', w1.grad, w3.grad, tol=1e-4)
     assert torch.equal(bits1.cpu().to(torch.float64), torch.sign(gamma3.detach().view(-1)).cpu())
     assert abs(float(loss1.detach()) - float(loss3.detach())) <= 1e-5 * max(1.0, abs(float(loss3.detach())))
-    print('stub ok: 8 outputs bit-identical with the product binding, 5 within 1e-5 of stock ATen (f64)')
-
-
-if __name__ == '__main__':
-    main()

@@ -1062,18 +1062,28 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
     from deepipr_amd.flat_sgd import FlatSGD
     from deepipr_amd import passport_ops
     monkeypatch.setenv('DEEPIPR_FORCE_DDP', '1')
-    monkeypatch.setattr(passport_ops.kernels, 'allow_sync', True)      # FlatSGD clears it; restored afterwards
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1)
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
         finals = []
-        for graphed in (False, True):
+        for graphed in (False, True, 'staged'):
             prod, _ref, x, y = _fullsize_pair(False, 32, 10)
             x, y = x.to(DEV), y.to(DEV)
             opt = FlatSGD(prod.parameters(), **SGD)
             assert opt.comm and len(opt._buckets) >= 3
-            if graphed:
+            if graphed == 'staged':
+                # the default with several GPUs: one graph per backward stage, bucket all-reduces launched between the
+                # replays on a side stream (experiments/staged.py)
+                from deepipr_amd.experiments.staged import StagedStep
+                g = StagedStep(train_step_v1, prod, opt, x, y, graph=True, warmup=0)
+                plan = g.describe()
+                assert [s['cut'] for s in plan['stages']] == ['layer4.1', 'layer4.0', 'layer3.0', None], plan
+                assert [s['split_channel_kernels'] for s in plan['stages']] == [False, False, False, True], plan
+                assert opt._mode == 'staged' and len(g._graphs) == 4
+                for i in range(3):
+                    g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
+            elif graphed:
                 g = GraphedTrainStep(train_step_v1, prod, opt, x, y, warmup=0, optimizer_in_graph=False)
                 for i in range(3):
                     g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
@@ -1085,6 +1095,8 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
         for k in finals[0]:
             if finals[0][k].dtype.is_floating_point:
                 assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+                assert torch.allclose(finals[0][k], finals[2][k], rtol=1e-3, atol=1e-5), k
+        passport_ops.kernels.check_exchange()
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
         dist.destroy_process_group()

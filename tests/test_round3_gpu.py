@@ -1,0 +1,216 @@
+"""GPU parity tests added in round 3 (every call goes through the C ABI -> HIP kernels).
+
+  * whole-net backward at 1e-4 of scale: ResNet18 V1 (batch 128) and V2 (batch 32) against the float64 oracle with the
+    ReLU kinks gated out in BOTH nets (the model-level gradient bars were 2-3 orders looser than
+    the north-star number because one flipped mask perturbs everything upstream)
+  * the batched passport GEMV / rank-2 update (several layers per launch) against the numpy oracle, bits exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+from tests.test_round2_gpu import pinned_miopen
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def K():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from deepipr_amd import _lib, passport_ops
+    _lib.lib()
+    assert type(passport_ops.kernels).__name__ == 'HipKernels'
+    return passport_ops.kernels
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- batched GEMV pair
+GEMV_BATCHES = [
+    [(512, 2304), (512, 4608), (512, 256), (512, 4608), (512, 4608)],     # ResNet18 layer4 (config R / P)
+    [(384, 1728), (256, 3456), (256, 2304)],                              # AlexNet features 4-6 (config A)
+    [(5, 7), (64, 75), (33, 1028), (2, 5124), (1, 4)],                    # K % 4 != 0, K beyond one trip, odd row counts
+    [(512, 4608)],                                                        # n = 1 (what the single-layer entry points call)
+]
+
+
+@pytest.mark.parametrize('batch', GEMV_BATCHES)
+def test_gamma_beta_multi_matches_the_oracle_and_the_single_layer_calls(K, batch):
+    """deepipr_gamma_beta_fwd_multi / _bwd_multi: gamma, beta of every layer of a batch in one launch, and the rank-2
+    update of all their dW in one launch (fresh and accumulate form) -- against the float64 contraction W . m that
+    oracle/np_passport.py: gamma_beta_fwd reduces to for pooled keys (gamma within 1 ulp-ish of the f64 sum: 2e-7 relative to sum |W m|; signature bits exact) and bit-identical to the per-layer
+    calls (the same kernel with n = 1)."""
+    rs = np.random.RandomState(len(batch) * 1000 + batch[0][1])
+    ws = [dev(rs.standard_normal((co, k)) * 0.05) for co, k in batch]
+    ms = [dev(rs.uniform(-1, 1, (2, k)), torch.float64) for co, k in batch]
+    got = K.gamma_beta_fwd_multi(ws, ms)
+    for (g, b), w, m in zip(got, ws, ms):
+        w64, m64 = host(w).astype(np.float64), host(m)
+        g64, b64 = w64 @ m64[0], w64 @ m64[1]
+        mag = np.abs(w64) @ np.abs(m64[0]) + 1e-30
+        assert np.all(np.abs(host(g) - g64) <= 2e-7 * mag + 1e-30)
+        assert np.all(np.abs(host(b) - b64) <= 2e-7 * (np.abs(w64) @ np.abs(m64[1])) + 1e-30)
+        meaningful = np.abs(g64) > 8 * np.finfo(np.float32).eps * mag
+        assert np.array_equal(np.sign(host(g))[meaningful], np.sign(g64)[meaningful])       # signature bits
+        g1, b1 = K.gamma_beta_fwd(w, m)
+        assert torch.equal(g1, g) and torch.equal(b1, b)
+    dgs = [dev(rs.standard_normal(co)) for co, k in batch]
+    dbs = [dev(rs.standard_normal(co)) for co, k in batch]
+    fresh = K.gamma_beta_bwd_multi(dgs, dbs, ms, [torch.full_like(w, float('nan')) for w in ws], False)
+    for dw, dg, db, m, w in zip(fresh, dgs, dbs, ms, ws):
+        m32 = host(m).astype(np.float32)
+        ref = (host(dg)[:, None].astype(np.float64) * m32[0][None, :] + host(db)[:, None].astype(np.float64) * m32[1][None, :])
+        assert np.abs(host(dw) - ref).max() <= 2e-6 * (np.abs(ref).max() + 1e-30)
+        assert torch.equal(dw, K.gamma_beta_bwd(dg, db, m, tuple(w.shape)))
+    base = [dev(rs.standard_normal(tuple(w.shape))) for w in ws]
+    acc = K.gamma_beta_bwd_multi(dgs, dbs, ms, [t.clone() for t in base], True)
+    for a, t, f in zip(acc, base, fresh):
+        assert torch.equal(a, t + f)                                  # one rounding of the same sum
+
+
+# ----------------------------------------------------------------------------- whole net, tight
+class _RecordingF:
+    """torch.nn.functional for oracle/torch_ref.py with relu() recording, per layer, which pre-activations sit within
+    `tol` of the ReLU kink."""
+
+    def __init__(self, state, tol):
+        self.state, self.tol = state, tol
+
+    def __getattr__(self, name):
+        return getattr(torch.nn.functional, name)
+
+    def relu(self, t, *a, **k):
+        name = self.state['current']
+        if name is not None and t.dim() == 4:
+            self.state['near'].setdefault(name, []).append(t.detach().abs() < self.tol)
+        return torch.relu(t)
+
+
+def _layer_modules(net, types):
+    return [(k, m) for k, m in net.named_modules() if isinstance(m, types)]
+
+
+@pytest.mark.miopen_pinned
+@pytest.mark.parametrize('private', [False, True])
+def test_whole_net_backward_within_1e4_with_relu_kinks_gated(private, monkeypatch):
+    """ResNet18 V1 (batch 128) / V2 (batch 32, both branches, one backward) on the GPU against the float64 oracle
+    (stock ATen, oracle/torch_ref.py, same weights / keys / batch): logits, losses and EVERY parameter gradient within
+    1e-4 of its scale -- the north-star tolerance applied to a whole-net backward pass.
+
+    Two correct implementations may mask an activation that sits within rounding of a ReLU kink differently, and one
+    flipped mask perturbs every gradient upstream of it at the 1e-3 level (tests/triage/debug_hooks.py), which is why
+    the older model-level tests carry loose bounds.  Here the kinks are removed from the comparison the way
+    test_passport_block_backward_chain_at_config_R_shape does for one layer: a first float64 forward finds, per layer,
+    the pre-activations within 1e-4 of zero; both nets then run with those elements of the layer's output gated to
+    zero (output * keep), so neither value nor gradient passes through a near-kink element.  Gated outputs are 0 or
+    >= 1e-4, so the block tails relu(a + b) have no near-kink elements of their own.  The product runs with the
+    separate tail kernels (DEEPIPR_TAIL_FUSION=0) so that every layer output exists to be gated; the fused tails are
+    bit-identical to them (test_tail_fusion_is_bit_identical_at_model_level)."""
+    from deepipr_amd.models._builders import PASSPORT_TYPES
+    from deepipr_amd.models.layers.conv2d import ConvBlock
+    from tests.test_parity_gpu import _fullsize_pair
+    monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
+    tol = 1e-4
+    n, ncls = (32, 100) if private else (128, 10)
+    prod, ref, x, y = _fullsize_pair(private, n, ncls)
+    ref = ref.double().to(DEV)
+    xg, yg = x.to(DEV), y.to(DEV)
+    x64 = xg.double()
+    ce = torch.nn.functional.cross_entropy
+    inds = (0, 1) if private else (None,)
+
+    def ref_forward():
+        return [ref(x64) if i is None else ref(x64, ind=i) for i in inds]
+
+    # ---- pass 1: where are the kinks (float64, no grad; the norm buffers are restored afterwards)
+    state = {'current': None, 'near': {}}
+    ref_layers = _layer_modules(ref, (torch_ref.ConvBlockRef, torch_ref.PassportLayerRef))
+    saved = {k: v.clone() for k, v in ref.state_dict().items()}
+    hooks = []
+    for name, m in ref_layers:
+        hooks.append(m.register_forward_pre_hook(lambda _m, _i, name=name: state.__setitem__('current', name)))
+        hooks.append(m.register_forward_hook(lambda _m, _i, _o: state.__setitem__('current', None)))
+    monkeypatch.setattr(torch_ref, 'F', _RecordingF(state, tol))
+    with torch.no_grad():
+        ref_forward()
+    monkeypatch.undo()
+    monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
+    for h in hooks:
+        h.remove()
+    ref.load_state_dict(saved)
+    near = state['near']
+    assert set(near) == {k for k, _ in ref_layers} and all(len(v) == len(inds) for v in near.values())
+    gated = sum(int(t.sum()) for v in near.values() for t in v)
+    total = sum(t.numel() for v in near.values() for t in v)
+    assert 0 < gated < 2e-3 * total, (gated, total)
+
+    # ---- pass 2: both nets with the near-kink outputs gated
+    def gate(masks, dtype):
+        calls = {'n': 0}
+
+        def hook(_m, _i, out):
+            keep = (~masks[calls['n'] % len(masks)]).to(dtype)
+            calls['n'] += 1
+            if isinstance(out, tuple):                          # a layer whose output is handed out twice (the stem)
+                return tuple(o * keep for o in out)
+            return out * keep
+        return hook
+    for name, m in ref_layers:
+        m.register_forward_hook(gate(near[name], torch.float64))
+    prod_layers = dict(_layer_modules(prod, PASSPORT_TYPES + (ConvBlock,)))
+    assert set(prod_layers) == set(near)
+    # ConvBlocks: a module hook sees the layer's own output (the tail add happens outside the module call).  Passport
+    # layers add the residual INSIDE their module call (_forward), so their own output is gated where it is produced.
+    from deepipr_amd.models.layers._passport_base import PassportLayerBase
+    gates = {}
+    for name, m in prod_layers.items():
+        if isinstance(m, ConvBlock):
+            m.register_forward_hook(gate(near[name], torch.float32))
+        else:
+            gates[id(m)] = gate(near[name], torch.float32)
+    inner = PassportLayerBase._layer
+
+    def gated_layer(self, x_in, force_passport, ind, residual):
+        out = inner(self, x_in, force_passport, ind, residual)
+        g = gates.get(id(self))
+        return out if g is None else g(self, None, out)
+    monkeypatch.setattr(PassportLayerBase, '_layer', gated_layer)
+
+    outs_r = ref_forward()
+    loss_r = sum(ce(o, yg) for o in outs_r)
+    sign_r = sum(m.loss for m in torch_ref.sign_losses(ref) if isinstance(m.loss, torch.Tensor))
+    (loss_r + sign_r).backward()
+    with pinned_miopen():
+        outs_p = [prod(xg) if i is None else prod(xg, ind=i) for i in inds]
+        loss_p = sum(ce(o, yg) for o in outs_p)
+        if private:
+            sign_p = sum(m.sign_loss_private.loss for m in prod.modules() if hasattr(m, 'sign_loss_private'))
+        else:
+            sign_p = sum(m.sign_loss.loss for m in prod.modules()
+                         if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+        (loss_p + sign_p).backward()
+        torch.cuda.synchronize()
+
+    for op, orf in zip(outs_p, outs_r):
+        scale = max(1.0, float(orf.abs().max()))
+        assert float((op.double() - orf).abs().max()) <= 1e-4 * scale
+    assert abs(float(loss_p) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
+    assert abs(float(sign_p) - float(sign_r)) <= 1e-4 * max(1.0, abs(float(sign_r)))
+    gp = dict(prod.named_parameters())
+    worst = (0.0, None)
+    for name, p in ref.named_parameters():
+        assert p.grad is not None and gp[name].grad is not None, name
+        scale = float(p.grad.abs().max()) + 1e-30
+        rel = float((gp[name].grad.double() - p.grad).abs().max()) / scale
+        worst = max(worst, (rel, name))
+        assert rel <= 1e-4, (name, rel, scale)
+    print('whole-net backward, kinks gated (%d of %d activations): worst gradient error %.2e of scale (%s)'
+          % (gated, total, worst[0], worst[1]))

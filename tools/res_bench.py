@@ -22,7 +22,7 @@ def run(shape, resident, sync=True, reps=40):
     g, b = torch.randn(c, device=dev), torch.randn(c, device=dev)
     rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
     _lib.set_resident(resident)
-    K.allow_sync = sync
+    K.set_user_sync(sync)
 
     def once():
         out = K.passport_bn_fwd(x, None, None, g, b, None, 0.0, True, rm, rv, None, 0.1, 1e-5, True)
@@ -37,7 +37,7 @@ def run(shape, resident, sync=True, reps=40):
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     _lib.set_resident(True)
-    K.allow_sync = True
+    K.set_user_sync(True)
     fwd = sum(1000.0 * prof[k][0] / reps for k in ('bn_res_fwd', 'bn_stats', 'gamma_beta_fwd', 'bn_affine_fwd'))
     bwd = sum(1000.0 * prof[k][0] / reps for k in ('bn_res_bwd', 'bn_bwd_reduce', 'passport_bwd_finish', 'bn_affine_bwd'))
     return fwd, bwd
