@@ -58,8 +58,6 @@ SIGNATURES = {
     'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
     'deepipr_sgd_momentum_chunk': (_int, []),
     'deepipr_sgd_momentum_step_multi': (_int, [_f32p, _f32p, _vp, _int, _sz, _f32p, _vp]),
-    'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
-    'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_passport_bn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_bn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _f32p, _f32p, _vp,
                                        _flt, _flt, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p,
@@ -78,6 +76,11 @@ SIGNATURES = {
                                        _vp]),
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
+}
+# exported by the measurement / test build only (libdeepipr_hip_trace.so, DEEPIPR_LIB=...): bound when present
+TEST_HOOK_SIGNATURES = {
+    'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
+    'deepipr_debug_trace': (_int, [_vp]),
 }
 ABI_VERSION = 5
 SYNC_WORDS = 2 * 256 * 30 * 4 + 16     # DEEPIPR_SYNC_WORDS
@@ -122,6 +125,11 @@ def lib():
             raise HipLibraryMissing('deepipr_amd: %s does not export %s (stale build?)' % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in TEST_HOOK_SIGNATURES.items():
+        fn = getattr(handle, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if handle.deepipr_abi_version() != ABI_VERSION:
         raise HipLibraryMissing('deepipr_amd: %s has ABI version %d, expected %d' %
                                 (LIB_PATH, handle.deepipr_abi_version(), ABI_VERSION))
@@ -141,8 +149,16 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd']
 
 
+def has_test_hooks():
+    return hasattr(lib(), 'deepipr_debug_tune')
+
+
 def debug_tune(key, value):
-    """Tuning / test knobs of the single-pass kernels (include/deepipr_hip.h: deepipr_debug_tune)."""
+    """Planning knobs / time-out test hooks of the single-pass kernels -- measurement / test build only
+    (DEEPIPR_LIB=.../libdeepipr_hip_trace.so; include/deepipr_hip.h: deepipr_debug_tune)."""
+    if not has_test_hooks():
+        raise RuntimeError('deepipr_debug_tune is not part of the production library: load the test build '
+                           '(make -C deepipr_amd/csrc trace; DEEPIPR_LIB=.../libdeepipr_hip_trace.so)')
     check(lib().deepipr_debug_tune(key.encode(), int(value)), 'debug_tune')
 
 

@@ -427,6 +427,91 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta_multi(GemvBatch B) {
     }
 }
 
+// The same GEMV with the pooled vectors staged through LDS: in the register form above every workgroup pulls both f64
+// vectors (16 B per float of a row: 4x the row's own bytes) from L2 for only RPW rows -- 1 280 workgroups x 73 KB =
+// 94 MB of L2 reads next to 33.6 MB of HBM reads for ResNet18's layer4, which measured L2-bound (11.6 us, 0.36 of HBM
+// peak).  Here a workgroup owns 2*RP rows and walks K in chunks of kGemvChunk float4 (two trips of the 256 threads):
+// the chunk of both vectors goes to LDS once (32 KB), every row of the workgroup reads it from there.  Thread t still
+// owns the float4 positions q = t (mod 256) in ascending order and the workgroup combine is the same
+// (wave butterfly, then (w0 + w1) + (w2 + w3)): results are BIT-IDENTICAL to the register form.
+constexpr int kGemvChunk = 2 * kThreads;           // float4 per chunk of K
+
+template <int RP>
+__global__ __launch_bounds__(kThreads) void k_gamma_beta_multi_lds(GemvBatch B) {
+    __shared__ __attribute__((aligned(16))) double sm[2][kGemvChunk * 4];      // [scale | bias][chunk], 32 KB
+    __shared__ double red[RP * 2][2][kThreads / kWave];
+    int li = 0;
+    for (int i = 1; i < B.n; ++i)
+        if (static_cast<int>(blockIdx.x) >= B.L[i].block0) li = i;
+    const float *W = B.L[li].W;
+    const double *m = B.L[li].m;
+    const int Co = B.L[li].Co, K = B.L[li].K;
+    const int co0 = (static_cast<int>(blockIdx.x) - B.L[li].block0) * (2 * RP);
+    const int K4 = K / 4;
+    const int t = threadIdx.x;
+    double acc[RP * 2][2];
+    const float4 *row[RP * 2];
+#pragma unroll
+    for (int r = 0; r < RP * 2; ++r) {
+        acc[r][0] = 0.0;
+        acc[r][1] = 0.0;
+        row[r] = reinterpret_cast<const float4 *>(W + static_cast<size_t>(min(co0 + r, Co - 1)) * K);
+    }
+    for (int base = 0; base < K4; base += kGemvChunk) {
+        const int n4 = min(kGemvChunk, K4 - base);          // float4 positions in this chunk
+        float4 w[RP * 2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + t;
+#pragma unroll
+            for (int r = 0; r < RP * 2; ++r)
+                w[r][p] = q < n4 ? row[r][base + q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();                                     // the previous chunk's readers are done
+        for (int i = t; i < 2 * n4; i += kThreads) {          // double2 units of the two vectors' chunks
+            reinterpret_cast<double2 *>(sm[0])[i] = reinterpret_cast<const double2 *>(m + 4 * static_cast<size_t>(base))[i];
+            reinterpret_cast<double2 *>(sm[1])[i] = reinterpret_cast<const double2 *>(m + K + 4 * static_cast<size_t>(base))[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + t;
+            if (q < n4) {
+                const double2 s0 = reinterpret_cast<const double2 *>(sm[0])[2 * q];
+                const double2 s1 = reinterpret_cast<const double2 *>(sm[0])[2 * q + 1];
+                const double2 b0 = reinterpret_cast<const double2 *>(sm[1])[2 * q];
+                const double2 b1 = reinterpret_cast<const double2 *>(sm[1])[2 * q + 1];
+#pragma unroll
+                for (int r = 0; r < RP * 2; ++r) {
+                    acc[r][0] = fma(static_cast<double>(w[r][p].x), s0.x, acc[r][0]);
+                    acc[r][0] = fma(static_cast<double>(w[r][p].y), s0.y, acc[r][0]);
+                    acc[r][0] = fma(static_cast<double>(w[r][p].z), s1.x, acc[r][0]);
+                    acc[r][0] = fma(static_cast<double>(w[r][p].w), s1.y, acc[r][0]);
+                    acc[r][1] = fma(static_cast<double>(w[r][p].x), b0.x, acc[r][1]);
+                    acc[r][1] = fma(static_cast<double>(w[r][p].y), b0.y, acc[r][1]);
+                    acc[r][1] = fma(static_cast<double>(w[r][p].z), b1.x, acc[r][1]);
+                    acc[r][1] = fma(static_cast<double>(w[r][p].w), b1.y, acc[r][1]);
+                }
+            }
+        }
+    }
+    const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int r = 0; r < RP * 2; ++r) {
+        const double a = wave_sum(acc[r][0]), b = wave_sum(acc[r][1]);
+        if (lane == 0) {
+            red[r][0][wave] = a;
+            red[r][1][wave] = b;
+        }
+    }
+    __syncthreads();
+    if (t < RP * 2 * 2) {
+        const int r = t >> 1, which = t & 1;
+        const double v = (red[r][which][0] + red[r][which][1]) + (red[r][which][2] + red[r][which][3]);
+        if (co0 + r < Co) (which ? B.L[li].beta : B.L[li].gamma)[co0 + r] = static_cast<float>(v);
+    }
+}
+
 // The rank-2 update dW[co, :] (+)= dgamma[co] * m_scale + dbeta[co] * m_bias of several layers in one launch, the
 // accumulate form with all of a thread's loads of dW in flight before the first store.
 struct Rank2Layer {
@@ -1500,11 +1585,23 @@ struct ResPlan {
     int G, q4, gq;        // channels per workgroup, float4 per plane, G*q4
     int blocks;           // (C/G) * S
     FastDiv gqdiv;
+#ifdef DEEPIPR_TEST_HOOKS
+    // Measurement / test build only (`make trace`: libdeepipr_hip_trace.so; the production library has none of this):
     unsigned spin;        // bound of the exchange wait (kSpinLimit; tests shorten it)
-    int drop;             // test hook: this slice never publishes its partial sums (-1 = none)
+    int drop;             // this slice never publishes its partial sums (-1 = none): forces the time-out path
     int xcd_map;          // slices of one channel are placed on workgroups with equal blockIdx % 8 (one XCD)
-    unsigned long long *trace;   // DEEPIPR_TRACE builds only: [block][8] wall-clock stamps of the kernel's phases
+    unsigned long long *trace;   // [block][8] wall-clock stamps of the kernel's phases
+#endif
 };
+#ifdef DEEPIPR_TEST_HOOKS
+#define DEEPIPR_RES_SPIN(pl) ((pl).spin)
+#define DEEPIPR_RES_DROP(pl) ((pl).drop)
+#define DEEPIPR_RES_XCD(pl) ((pl).xcd_map)
+#else
+#define DEEPIPR_RES_SPIN(pl) (kSpinLimit)
+#define DEEPIPR_RES_DROP(pl) (-1)
+#define DEEPIPR_RES_XCD(pl) (0)
+#endif
 
 // Phase stamps of one workgroup (thread 0): 0 entry, 1 loads consumed + block sums done, 2 exchange done,
 // 3 channel table ready (forward), 4 all stores issued.  Compiled in only with -DDEEPIPR_TRACE (`make trace` builds
@@ -1636,7 +1733,7 @@ __device__ __forceinline__ void res_exchange(double &s0, double &s1, const ResXc
 // for speed only), so the S slices of a channel are given indices with equal b % 8: their granules stay in one L2.
 __device__ __forceinline__ void res_block_coords(const ResPlan &pl, int &cb, int &s) {
     const int b = blockIdx.x;
-    if (pl.xcd_map) {
+    if (DEEPIPR_RES_XCD(pl)) {
         const int span = 8 * pl.S, g = b / span, r = b - g * span;
         s = r >> 3;
         cb = g * 8 + (r & 7);
@@ -1750,7 +1847,7 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     res_stamp(pl, 1);
     if (pl.S > 1) {                                   // G == 1 here
         if (t < kWave) {
-            res_exchange(s1, s2, xc, s, pl.S, sync, pl.spin, pl.drop);
+            res_exchange(s1, s2, xc, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
             if (t == 0) {
                 xch[0] = s1;
                 xch[1] = s2;
@@ -1890,7 +1987,7 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
     res_stamp(pl, 1);
     if (pl.S > 1) {
         if (t < kWave) {
-            res_exchange(ag, ab, xc, s, pl.S, sync, pl.spin, pl.drop);
+            res_exchange(ag, ab, xc, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
             if (t == 0) {
                 xch[0] = ag;
                 xch[1] = ab;
@@ -2260,8 +2357,12 @@ __global__ __launch_bounds__(kThreads) void k_ce_rows(const float *__restrict__ 
     if (lane == 0) {
         const double l = static_cast<double>(mx) + log(sum);
         lse[n] = static_cast<float>(l);
-        part[2 * static_cast<size_t>(n) + 0] = l - static_cast<double>(row[t]);
-        part[2 * static_cast<size_t>(n) + 1] = (static_cast<long long>(arg) == t) ? 1.0 : 0.0;
+        // a label outside [0, C) (ATen: device assert; also F.cross_entropy's ignore_index = -100, which this head does
+        // not implement) must not read out of bounds and must not pass silently: the loss becomes NaN
+        const bool valid = t >= 0 && t < static_cast<long long>(C);
+        part[2 * static_cast<size_t>(n) + 0] = valid ? l - static_cast<double>(row[t])
+                                                     : __longlong_as_double(0x7ff8000000000000LL);
+        part[2 * static_cast<size_t>(n) + 1] = (valid && static_cast<long long>(arg) == t) ? 1.0 : 0.0;
     }
 }
 
@@ -2291,7 +2392,9 @@ __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float *__restrict__ d
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += step) {
         const int n = static_cast<int>(i / C), c = static_cast<int>(i - static_cast<size_t>(n) * C);
         const float p = expf(logits[i] - lse[n]);
-        dlogits[i] = scale * (p - (static_cast<long long>(c) == target[n] ? 1.0f : 0.0f));
+        const long long tn = target[n];
+        const float g = scale * (p - (static_cast<long long>(c) == tn ? 1.0f : 0.0f));
+        dlogits[i] = (tn >= 0 && tn < static_cast<long long>(C)) ? g : __int_as_float(0x7fc00000);   // invalid label: NaN row
     }
 }
 
@@ -2548,10 +2651,21 @@ int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *st
         rows += l.Co;
         bytes += 4.0 * static_cast<double>(l.Co) * l.K;
     }
-    // two rows of W per workgroup share the pooled vectors (half the L2 -> CU traffic) once that still leaves >= 4
-    // workgroups per CU
-    const int cus = device_cu_count();
-    const int rpw = rows >= 8ll * (cus > 0 ? cus : 256) ? 2 : 1;
+    const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    bool all_vec = true;
+    for (int i = 0; i < n; ++i)
+        all_vec = all_vec && layers[i].K % 4 == 0 && aligned16(layers[i].W) && aligned16(layers[i].m);
+    // rows per workgroup: LDS form (every layer 16-byte aligned with K % 4 == 0) 8 rows once that leaves >= 2
+    // workgroups per CU, else 4; register form (odd K) 2 rows once that leaves >= 4 workgroups per CU, else 1
+    int rows_per_wg;
+    if (all_vec) rows_per_wg = rows >= 16ll * cus ? 8 : 4;
+    else rows_per_wg = rows >= 8ll * cus ? 2 : 1;
+#ifdef DEEPIPR_TEST_HOOKS
+    if (const char *e = getenv("DEEPIPR_GEMV_ROWS")) {      // tuning (tools/gemv_bench.py): 1 / 2 = register form, 4 / 8 = LDS form
+        const int v = atoi(e);
+        if ((v == 1 || v == 2) || ((v == 4 || v == 8) && all_vec)) rows_per_wg = v;
+    }
+#endif
     GemvBatch B{};
     B.n = n;
     int blocks = 0;
@@ -2559,12 +2673,16 @@ int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *st
         const DeepiprGemvLayer &l = layers[i];
         B.L[i] = GemvLayer{l.W, l.m, l.gamma, l.beta, l.Co, l.K, blocks,
                            (l.K % 4 == 0 && aligned16(l.W) && aligned16(l.m)) ? 1 : 0};
-        blocks += (l.Co + rpw - 1) / rpw;
+        blocks += (l.Co + rows_per_wg - 1) / rows_per_wg;
     }
     ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
     prof.bytes = bytes;
-    if (rpw == 2) DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<2>), dim3(blocks), dim3(kThreads), st, B);
-    else DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<1>), dim3(blocks), dim3(kThreads), st, B);
+    switch (rows_per_wg) {
+        case 8: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi_lds<4>), dim3(blocks), dim3(kThreads), st, B); break;
+        case 4: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi_lds<2>), dim3(blocks), dim3(kThreads), st, B); break;
+        case 2: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<2>), dim3(blocks), dim3(kThreads), st, B); break;
+        default: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<1>), dim3(blocks), dim3(kThreads), st, B); break;
+    }
     return check_launch("gamma_beta_fwd");
 }
 
@@ -2787,22 +2905,32 @@ int device_cu_count() {
     return cache[dev] > 0 ? cache[dev] : 0;
 }
 
-// Tuning / test knobs of the single-pass kernels (deepipr_debug_tune); defaults are the shipped configuration.
+// Planning constants of the single-pass kernels.  Measured per shape with tools/res_tune.py
+// (profiles/r02_res_tune_granule_exchange.log):
+//  * split_full = 1: with the granule exchange at ~1.2 us, splitting C = 128 layers over 2 workgroups per channel
+//    (256 workgroups instead of 128) wins 3-12 %; it lost 0-10 % with the 4 us ticket exchange of round 1;
+//  * xcd_map = 0: putting a channel's slices on one XCD helps the plain layers by 2 % (exchange locality) but
+//    costs the tail-folded backward 9 % (31.2 -> 34.0 us): one XCD then streams addresses 8 MB apart through its
+//    L2 instead of neighbouring channels.  Tails carry most of the bytes, so slices stay on consecutive workgroups;
+//  * small_t = 1: 256-thread workgroups for slices of <= 2048 float4.
+// The PRODUCTION library has them as constants; the measurement / test build (`make trace`, -DDEEPIPR_TEST_HOOKS)
+// turns them into knobs (deepipr_debug_tune) next to the time-out test hooks and the phase stamps.
+#ifdef DEEPIPR_TEST_HOOKS
 struct ResTune {
-    // Measured per shape with tools/res_tune.py (profiles/r02_res_tune_granule_exchange.log):
-    //  * split_full = 1: with the granule exchange at ~1.2 us, splitting C = 128 layers over 2 workgroups per channel
-    //    (256 workgroups instead of 128) wins 3-12 %; it lost 0-10 % with the 4 us ticket exchange of round 1;
-    //  * xcd_map = 0: putting a channel's slices on one XCD helps the plain layers by 2 % (exchange locality) but
-    //    costs the tail-folded backward 9 % (31.2 -> 34.0 us): one XCD then streams addresses 8 MB apart through its
-    //    L2 instead of neighbouring channels.  Tails carry most of the bytes, so slices stay on consecutive workgroups.
     std::atomic<int> split_full{1};   // split channels over slices whenever they do not fill the chip (0: only below half)
     std::atomic<int> xcd_map{0};      // 1: slices of a channel on workgroups with equal blockIdx % 8
     std::atomic<int> small_t{1};      // 256-thread workgroups for slices of <= 2048 float4 (0: always 1024 threads)
     std::atomic<int> spin{static_cast<int>(kSpinLimit)};
     std::atomic<int> drop{-1};        // test hook: slice that never publishes its partial sums
-    std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace, DEEPIPR_TRACE builds)
+    std::atomic<unsigned long long *> trace{nullptr};   // phase stamps (deepipr_debug_trace)
 };
 ResTune g_tune;
+inline bool tune_split_full() { return g_tune.split_full.load(std::memory_order_relaxed) != 0; }
+inline bool tune_small_t() { return g_tune.small_t.load(std::memory_order_relaxed) != 0; }
+#else
+inline bool tune_split_full() { return true; }
+inline bool tune_small_t() { return true; }
+#endif
 
 // Can x[N][C][P] (and dy) be held in registers?  max_f4: float4 units a thread of a 1024-thread workgroup may keep.
 // (Two 512-thread workgroups per CU, with or without a delayed second cohort, were measured slower on every
@@ -2811,7 +2939,7 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     if (g_resident_mode.load(std::memory_order_relaxed) == 0 || P % 4 != 0) return false;
     const int cus = device_cu_count();
     if (cus <= 0) return false;
-    const bool split_full = g_tune.split_full.load(std::memory_order_relaxed) != 0;
+    const bool split_full = tune_split_full();
     ResPlan pl{};
     pl.q4 = P / 4;
     int G = 1;
@@ -2837,7 +2965,7 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     pl.nps = (N + S - 1) / S;
     pl.blocks = (C / G) * S;
     const long long units = static_cast<long long>(pl.nps) * pl.gq;
-    pl.T = (S == 1 && units <= 8 * 256 && g_tune.small_t.load(std::memory_order_relaxed)) ? 256 : 1024;
+    pl.T = (S == 1 && units <= 8 * 256 && tune_small_t()) ? 256 : 1024;
     if (pl.blocks * 4 < cus) return false;                   // too few workgroups to be worth a single pass
     const long long need = (units + pl.T - 1) / pl.T;
     static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -2849,10 +2977,12 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         }
     if (pl.F4 == 0) return false;
     pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
+#ifdef DEEPIPR_TEST_HOOKS
     pl.spin = static_cast<unsigned>(g_tune.spin.load(std::memory_order_relaxed));
     pl.drop = g_tune.drop.load(std::memory_order_relaxed);
     pl.xcd_map = (S > 1 && (C / G) % 8 == 0 && g_tune.xcd_map.load(std::memory_order_relaxed)) ? 1 : 0;
     pl.trace = g_tune.trace.load(std::memory_order_relaxed);
+#endif
     *out = pl;
     return true;
 }
@@ -2969,6 +3099,7 @@ int deepipr_passport_bn_slices(int N, int C, int HW) {
     return S;
 }
 
+#ifdef DEEPIPR_TEST_HOOKS
 int deepipr_debug_tune(const char *key, int value) {
     if (!key) return fail(DEEPIPR_EINVAL, "debug_tune: null key");
     const std::string k(key);
@@ -2985,6 +3116,7 @@ int deepipr_debug_trace(unsigned long long *device_buffer) {
     g_tune.trace.store(device_buffer);
     return DEEPIPR_OK;
 }
+#endif
 
 int deepipr_set_resident(int mode) {
     if (mode != 0 && mode != 1) return fail(DEEPIPR_EINVAL, "set_resident: mode must be 0 or 1");

@@ -153,7 +153,13 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
     model = build_model(args, private, ncls, device)
     passport = private or args['train_passport']
     if passport:
-        install_keys(args, model, valid_loader, ncls, device, next(iter(train_loader))[0])
+        # the passport images come from the validation set, or -- --use-trigger-as-passport -- from the trigger set
+        # (experiments/classification.py:37-40: passport_data = prepare_wm(...) instead of valid_data)
+        passport_loader = valid_loader
+        if args.get('use_trigger_as_passport'):
+            passport_loader = wm_loader if wm_loader is not None else \
+                SyntheticLoader(100, 2, size, ncls, device, seed=99)      # the trigger set's synthetic stand-in
+        install_keys(args, model, passport_loader, ncls, device, next(iter(train_loader))[0])
     # SGD(momentum .9, weight decay 1e-4) as experiments/classification.py:47-50.  Default: FlatSGD (flat buffers,
     # bucketed RCCL all-reduce overlapped with backward, one fused HIP kernel); --ddp: DistributedDataParallel +
     # torch's SGD.

@@ -11,6 +11,7 @@ import torch.nn as nn
 from deepipr_amd import cuts
 from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
+from deepipr_amd.passport_ops import gamma_beta_batch
 
 _WIDTHS = {0: 64, 2: 192, 4: 384, 5: 256, 6: 256}
 _POOL_AT = (1, 3, 7)
@@ -61,8 +62,10 @@ class AlexNetPassport(nn.Module):
         return [('features.5', list(self.features[5:]) + [self.classifier]), (None, list(self.features[:5]))]
 
     def forward(self, x, force_passport=False, ind=0):
-        for i, m in enumerate(self.features):
-            if i == 5:
-                x = cuts.mark('features.5', x)
-            x = run_layer(m, x, force_passport, ind)
+        layers = [m for m in self.features if isinstance(m, PASSPORT_TYPES)] if x.is_cuda else ()
+        with gamma_beta_batch(layers, force_passport, ind):     # all passport layers' gamma / beta in one GEMV launch
+            for i, m in enumerate(self.features):
+                if i == 5:
+                    x = cuts.mark('features.5', x)
+                x = run_layer(m, x, force_passport, ind)
         return self.classifier(x.view(x.size(0), -1))

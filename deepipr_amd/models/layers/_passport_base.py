@@ -215,96 +215,86 @@ class PassportLayerBase(nn.Module):
 
     def _conv_inside(self, x):
         """The data convolution can run inside the fused node (passport_ops._PassportBNLayer, `conv`): a plain
-        bias-free conv nobody hooked, fp32 input (host tensors are refused by the kernels further down)."""
+        bias-free conv nobody hooked or re-parametrised -- `self.weight` must still BE conv.weight (it is an alias taken
+        in __init__, passportconv2d.py:21; after `conv.weight = nn.Parameter(...)` or torch.nn.utils.parametrize in a
+        fine-tune / attack script the node would otherwise convolve with the stale tensor) -- and a dense fp32 GPU
+        input."""
         c = self.conv
-        return (self.fuse_conv and x.dtype == torch.float32 and x.dim() == 4 and c.bias is None
+        return (self.fuse_conv and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and c.bias is None
+                and self.weight is c._parameters.get('weight')
                 and c.groups == 1 and tuple(c.dilation) == (1, 1) and c.padding_mode == 'zeros'
                 and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks)
+
+    def _plan(self, x, public):
+        """Which kernels take this call: -> (form, conv_inside).
+        form 'bn'   BatchNorm(affine=False) folded into the single-pass / three-launch kernels (deepipr_passport_bn_*)
+             'gn'   GroupNorm / InstanceNorm folded in (deepipr_passport_gn_*), when the (sample, group) chunk fits
+             'none' norm_type 'none': nothing between conv and affine (deepipr_passport_fwd / _bwd)
+             'lib'  the library norm, then the unfused affine kernels
+        conv_inside: the data convolution runs inside the fused autograd node, so that the shared weight's three-way
+        gradient is formed in MIOpen's wgrad buffer (passport branch only; see _conv_inside).  A new fused form is one
+        more line here and one more entry in _layer's dispatch."""
+        norm = self.bn
+        inside = (not public) and self._conv_inside(x)
+        if self.fuse_norm and P.bn_is_fusable(norm):
+            return 'bn', inside
+        if (self.fuse_norm and not getattr(norm, 'affine', False) and P.norm_groups(norm)
+                and x.dim() == 4 and P.gn_supported_shape(norm, P.conv_out_shape(x, self.conv))):
+            return 'gn', inside
+        if isinstance(norm, nn.Sequential) and len(norm) == 0:
+            return 'none', inside
+        return 'lib', False
 
     def _layer(self, x, force_passport, ind, residual):
         self.ensure_key(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
         p_bias = self._use_param(self.bias, force_passport, ind)
-        sl = self._sign()
-        if (self.fuse_norm and P.bn_is_fusable(self.bn) and not p_scale and not p_bias and self._conv_inside(x)):
-            # passport branch with the data convolution inside the fused node: the shared weight's three-way
-            # gradient is formed in MIOpen's wgrad buffer (deepipr_gamma_beta_bwd_acc), no extra dW + add pass
-            oshape = P.conv_out_shape(x, self.conv)
-            tail = residual if (residual is not None and P.bn_tail_fusable(self.bn, oshape)) else None
-            skey, key, m, stride, pad = self._pooled_means()
-            y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad, tail, conv_inside=True)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        passport_branch = not p_scale and not p_bias
-        inside = passport_branch and self._conv_inside(x)
-        if (inside and self.fuse_norm and self.bn is not None and not getattr(self.bn, 'affine', False)
-                and P.norm_groups(self.bn) and P.gn_supported_shape(self.bn, P.conv_out_shape(x, self.conv))):
-            # GroupNorm / InstanceNorm passport branch, data conv inside the fused node
-            skey, key, m, stride, pad = self._pooled_means()
-            y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad, conv_inside=True)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        if inside and isinstance(self.bn, nn.Sequential) and len(self.bn) == 0:
-            # norm_type 'none': nothing between conv and affine -- the unfused pair of kernels, data conv inside the node
-            skey, key, m, stride, pad = self._pooled_means()
-            y, gamma, _beta, loss, acc, _bits = P.passport_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad, conv_inside=True)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        x = self.conv(x)
-        if self.fuse_norm and P.bn_is_fusable(self.bn) and p_scale == p_bias:
-            # BatchNorm(affine=False) folded into the passport kernels: 3 launches forward, 3 backward,
-            # the normalised activation is never written (deepipr_passport_bn_fwd / _bwd)
-            tail = residual if (residual is not None and P.bn_tail_fusable(self.bn, x)) else None
-            if p_scale:
+        if p_scale != p_bias:                        # mixed (only one of scale / bias learnable): compose the operators
+            x = self.bn(self.conv(x))
+            return P.affine_relu(x, self.get_scale(force_passport, ind), self.get_bias(force_passport, ind), relu)
+        public = p_scale
+        form, inside = self._plan(x, public)
+        tail = None
+        if form == 'bn' and residual is not None and P.bn_tail_fusable(self.bn, P.conv_out_shape(x, self.conv)):
+            tail = residual                          # relu(layer + shortcut) folded into the layer's own kernels
+        if not inside:
+            x = self.conv(x)
+        if public:                                   # learnable scale / bias, no sign loss
+            if form == 'bn':
                 return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail)
-            skey, key, m, stride, pad = self._pooled_means()
-            # the loss is the SignLoss module's own (its b and alpha, sign_loss.py:27: set_b() and checkpoints count)
-            y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad, tail)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        if self.fuse_norm and self.bn is not None and p_scale == p_bias and P.gn_is_fusable(self.bn, x) \
-                and not getattr(self.bn, 'affine', False):
-            # GroupNorm / InstanceNorm folded in: one register-resident kernel per direction (deepipr_passport_gn_*)
-            if p_scale:
+            if form == 'gn':
                 return P.gn_affine_relu(x, self.scale, self.bias, self.bn, relu)
-            skey, key, m, stride, pad = self._pooled_means()
+            return P.affine_relu(self.bn(x), self.scale, self.bias, relu)
+        # passport branch.  The loss is the SignLoss module's own (its b and alpha, sign_loss.py:27: set_b() and
+        # checkpoints count)
+        sl = self._sign()
+        b, alpha = (sl.b, sl.alpha) if sl is not None else (None, 0.0)
+        skey, key, m, stride, pad = self._pooled_means()
+        if form == 'bn':
+            pre, self._gb_pre = self._gb_pre, None   # gamma / beta from the net's batched GEMV launch, if any
+            y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
+                x, self.weight, skey, key, b, m, self.bn, alpha, relu, stride, pad, tail, conv_inside=inside, pre=pre)
+        elif form == 'gn':
             y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m, self.bn,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        x = self.bn(x)
-        if p_scale and p_bias:                       # public branch: learnable affine, no sign loss
-            return P.affine_relu(x, self.scale, self.bias, relu)
-        if not p_scale and not p_bias:               # passport branch: the fused two-launch layer
-            skey, key, m, stride, pad = self._pooled_means()
+                x, self.weight, skey, key, b, m, self.bn, alpha, relu, stride, pad, conv_inside=inside)
+        else:
             y, gamma, _beta, loss, acc, _bits = P.passport_layer(
-                x, self.weight, skey, key, sl.b if sl is not None else None, m,
-                sl.alpha if sl is not None else 0.0, relu, stride, pad)
-            if sl is not None:
-                sl.reset()
-                sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
-            return y
-        # mixed (only one of scale / bias learnable): compose the unfused operators
-        gamma = self.get_scale(force_passport, ind)
-        beta = self.get_bias(force_passport, ind)
-        return P.affine_relu(x, gamma, beta, relu)
+                x if (inside or form == 'none') else self.bn(x), self.weight, skey, key, b, m, alpha, relu, stride, pad,
+                conv_inside=inside)
+        if sl is not None:
+            sl.reset()
+            sl.add_fused(gamma.view(1, -1, 1, 1), loss, acc)
+        return y
+
+    _gb_pre = None
+
+    def batched_gamma_beta_request(self, force_passport, ind):
+        """-> (weight, pooled means) when this layer's next forward will take the fused BatchNorm passport form, whose
+        gamma / beta the net may then compute for all such layers in ONE launch (passport_ops.gamma_beta_batch);
+        None otherwise."""
+        if (self._use_param(self.scale, force_passport, ind) or self._use_param(self.bias, force_passport, ind)
+                or not (self.fuse_norm and P.bn_is_fusable(self.bn)) or not self.weight.is_cuda
+                or self.get_bias_key() is None or self.get_scale_key() is None or self.requires_reset_key):
+            return None
+        return self.weight, self._pooled_means()[2]

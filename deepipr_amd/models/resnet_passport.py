@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from deepipr_amd import cuts
 from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer, run_layer_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
+from deepipr_amd.passport_ops import gamma_beta_batch
 
 
 class BasicPassportBlock(nn.Module):
@@ -136,13 +137,18 @@ class ResNetPassport(nn.Module):
         stages.append((None, [self.convbnrelu_1, self.layer1, self.layer2]))
         return stages
 
+    def passport_layers(self):
+        return [m for m in self.modules() if isinstance(m, PASSPORT_TYPES)]
+
     def forward(self, x, force_passport=False, ind=0):
-        out, skip = self._stem(x, force_passport, ind)
-        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
-            for bi, block in enumerate(layer):
-                if li >= 2 and bi <= 1:                      # the cut points backward_stages() names
-                    out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
-                out, skip = block.forward_pair(out, skip, force_passport, ind)
+        # gamma / beta of all passport layers in one GEMV launch, up front (they depend on weights and keys only)
+        with gamma_beta_batch(self.passport_layers() if x.is_cuda else (), force_passport, ind):
+            out, skip = self._stem(x, force_passport, ind)
+            for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+                for bi, block in enumerate(layer):
+                    if li >= 2 and bi <= 1:                      # the cut points backward_stages() names
+                        out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
+                    out, skip = block.forward_pair(out, skip, force_passport, ind)
         out = F.adaptive_avg_pool2d(out, (1, 1))
         return self.linear(out.view(out.size(0), -1))
 

@@ -394,11 +394,15 @@ class HipKernels:
         return v
 
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
-                        momentum, eps, training, margin=MARGIN, l2=L2, residual=None):
+                        momentum, eps, training, margin=MARGIN, l2=L2, residual=None, pre=False):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x; with `residual`
         (single-pass shapes only) y = relu(that + residual), the tail of a residual block.
+        pre=True: gamma_in / beta_in ARE the passport gamma / beta of `weight` (computed by the net's batched GEMV
+        launch): the layer's own GEMV is skipped, they are returned as gamma / beta.
         -> y, table[C,8], gamma, beta, loss, acc, bits  (gamma/beta None on the W-less public branch)."""
         dev = _chk(x, weight, residual)                     # the small per-channel vectors come from this module's own code
+        if pre:
+            pre_gamma, pre_beta, weight = gamma_in, beta_in, None
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         lib = _lib.lib()
@@ -429,6 +433,8 @@ class HipKernels:
         gamma = beta = loss = acc = None
         if weight is not None:
             gamma, beta = small[8 * c:9 * c], small[9 * c:10 * c]
+        elif pre:
+            gamma, beta = pre_gamma, pre_beta
         if b is not None:
             loss, acc = small[10 * c], small[10 * c + 1]
         return y, table, gamma, beta, loss, acc, bits
@@ -612,8 +618,9 @@ class PooledKeys:
     passport_attack_3.py:232-243, bumps the version); every code path of the layer that REPLACES or refills the
     keys (set_key, lazily drawn random keys, load_state_dict) clears the cache explicitly, because a new tensor
     can land on a freed tensor's address with an equal version, and writes through `.data` or a c10d broadcast do
-    not bump the version at all.  Outside autograd (no_grad / inference mode, where `.data`-style writes are the
-    norm) the means are recomputed on every call."""
+    not bump the version at all (whoever does that calls invalidate_key_cache(): distributed.broadcast_state, the
+    dry run of a graph capture).  Inference-mode tensors carry no version counter: for them the means are
+    recomputed on every call; under plain no_grad the cache is used like anywhere else."""
 
     def __init__(self):
         self._sig = None
@@ -806,9 +813,11 @@ class _PassportBNLayer(torch.autograd.Function):
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
         res = None if residual is None else residual.contiguous()
+        # weight AND gamma_in / beta_in: the latter are this weight's passport gamma / beta, already computed by the net's
+        # batched GEMV launch (gamma_beta_batch); backward is the passport branch's either way
         y, table, gamma, beta, loss, acc, bits = kernels.passport_bn_fwd(
             x, w, m, gi, bi, bb, float(alpha), relu, running_mean, running_var, nbt, float(momentum), float(eps),
-            training, residual=res)
+            training, residual=res, pre=(w is not None and gi is not None))
         ctx.tail = res is not None
         ctx.save_for_backward(x, w, table, m, bb, y if ctx.tail else None, x_in)
         ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
@@ -862,14 +871,54 @@ def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, st
                                   bn.num_batches_tracked if bn.training else None, residual, cfg)
 
 
-def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None, conv_inside=False):
+def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None, conv_inside=False,
+                      pre=None):
     """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False).
     conv_inside: `x` is the layer's INPUT; the data convolution runs inside the node and the shared weight's
     gradient is accumulated in place (see _PassportBNLayer).
+    pre = (gamma, beta) already computed for this weight by the batched GEMV launch (gamma_beta_batch).
     -> y, gamma, beta, loss, acc, bits; with `residual` y is the PAIR of handles of relu(layer + residual)."""
-    y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, None, None, b, m, bn, alpha, relu, stride,
+    pg, pb = pre if pre is not None else (None, None)
+    y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, pg, pb, b, m, bn, alpha, relu, stride,
                                                     pad, residual, (stride, pad) if conv_inside else None)
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
+
+
+class gamma_beta_batch:
+    """Context manager for a net's forward: gamma / beta of ALL its passport layers that will take the fused BatchNorm
+    form in ONE launch (deepipr_gamma_beta_fwd_multi) instead of one GEMV launch per layer -- ResNet18: the five
+    layer4 weights, 33.6 MB streamed once by a launch that fills the chip.  They depend only on the weights and the
+    cached pooled keys, so they are computed up front; each layer picks its pair up (PassportLayerBase._gb_pre) and its
+    autograd node treats it as its own GEMV's result (backward: the rank-2 update into the shared weight's gradient, as
+    before).  Pairs nobody used are dropped on exit.  DEEPIPR_NO_GEMV_BATCH=1 switches the batching off."""
+
+    def __init__(self, layers, force_passport=False, ind=0):
+        self.layers, self.args, self.used = layers, (force_passport, ind), []
+
+    def __enter__(self):
+        if os.environ.get('DEEPIPR_NO_GEMV_BATCH') == '1':
+            return self
+        reqs = []
+        for m in self.layers:
+            r = m.batched_gamma_beta_request(*self.args)
+            if r is not None:
+                reqs.append((m, r))
+        for lo in range(0, len(reqs), _lib.GEMV_MAX_LAYERS):
+            chunk = reqs[lo:lo + _lib.GEMV_MAX_LAYERS]
+            if len(chunk) < 2:
+                break                                  # a single layer: its own fused call does the same work
+            with torch.no_grad():
+                pairs = kernels.gamma_beta_fwd_multi([w.detach().contiguous() for _, (w, _m) in chunk],
+                                                     [mm for _, (_w, mm) in chunk])
+            for (m, _r), pair in zip(chunk, pairs):
+                m._gb_pre = pair
+                self.used.append(m)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.used:
+            m._gb_pre = None
+        return False
 
 
 def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False):

@@ -235,18 +235,21 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
 #define DEEPIPR_SYNC_WORDS (2 * 256 * 30 * 4 + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, + flags */
 #define DEEPIPR_SYNC_TIMEOUT_WORD (2 * 256 * 30 * 4)
 int deepipr_set_resident(int mode);
-/* Tuning / test knobs of the single-pass kernels, process-wide: "split_full" (default 1: split channels over
- * workgroups whenever they do not fill the chip; 0: only below half), "xcd_map" (default 0; 1: a channel's slices on
- * workgroups with equal index % 8), "exchange_spin"
- * (bound of the in-launch wait, <= 0 restores the default), "exchange_drop" (slice that never publishes its
- * partial sums: forces the time-out path in tests; -1 = none). */
+#ifdef DEEPIPR_TEST_HOOKS
+/* MEASUREMENT / TEST BUILD ONLY (libdeepipr_hip_trace.so, `make -C deepipr_amd/csrc trace`): the production library
+ * exports neither symbol and its kernels carry neither the knobs nor the hooks.
+ * deepipr_debug_tune: planning knobs of the single-pass kernels, process-wide: "split_full" (default 1: split
+ * channels over workgroups whenever they do not fill the chip; 0: only below half), "xcd_map" (default 0; 1: a
+ * channel's slices on workgroups with equal index % 8), "small_t"; and the time-out test hooks "exchange_spin" (bound
+ * of the in-launch wait, <= 0 restores the default) and "exchange_drop" (slice that never publishes its partial sums:
+ * forces the time-out path; -1 = none). */
 int deepipr_debug_tune(const char *key, int value);
-/* Phase tracing of the single-pass kernels (measurement only; effective in libdeepipr_hip_trace.so, `make trace`,
- * a no-op in the production library): while device_buffer != NULL, thread 0 of every
- * workgroup of k_bn_res_fwd / _bwd writes five 100 MHz wall-clock stamps to device_buffer[block][8]: entry, loads
- * consumed + workgroup sums formed, exchange done, channel table ready, all stores issued.  The buffer needs
- * 8 * 8 bytes per workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */
+/* Phase tracing of the single-pass kernels: while device_buffer != NULL, thread 0 of every workgroup of
+ * k_bn_res_fwd / _bwd writes five 100 MHz wall-clock stamps to device_buffer[block][8]: entry, loads consumed +
+ * workgroup sums formed, exchange done, channel table ready, all stores issued.  The buffer needs 8 * 8 bytes per
+ * workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */
 int deepipr_debug_trace(unsigned long long *device_buffer);
+#endif
 int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
 /* Workgroups per channel the single-pass kernels would use for this shape when exchange words are passed (the larger
  * of forward and backward; 1 = no in-launch exchange, also when the shape is not single-pass).  Host-side planning
@@ -330,7 +333,9 @@ int deepipr_sgd_momentum_step_multi(float *param, float *momentum_buf, const lon
  * dlogits[n][c] = dloss/N * (exp(logits[n][c] - lse[n]) - [c == target[n]]); `dloss` is a device scalar.
  * replaces: F.cross_entropy(pred, target) and accuracy(pred, target)[0] of experiments/trainer.py:136,149
  *           (trainer_private.py:161-166) -- log_softmax, nll_loss, topk, eq, sum, mul_ and their backward.
- * target: int64 class indices in [0, C) (the caller guarantees the range; no ignore_index).  Up to 2^20 logits
+ * target: int64 class indices in [0, C); no ignore_index.  A label outside the range (ATen would raise a device
+ * assert; F.cross_entropy's default ignore_index = -100 lands here too) is never dereferenced: its row's loss term
+ * is NaN -- so the mean loss is NaN -- and its dlogits row is NaN: the failure cannot pass silently.  Up to 2^20 logits
  * (deepipr_ce_top1_supported): larger problems return DEEPIPR_EUNSUPPORTED without enqueuing anything.
  * logits, dlogits [N][C] f32; loss, top1_pct: one float each; lse [N]. */
 int deepipr_ce_top1_supported(int N, int C);

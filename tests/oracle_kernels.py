@@ -107,7 +107,7 @@ class OracleKernels:
         return 3                      # the host logic is exercised as if every shape took the single-pass form
 
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
-                        momentum, eps, training, margin=npp.MARGIN, l2=npp.L2, residual=None):
+                        momentum, eps, training, margin=npp.MARGIN, l2=npp.L2, residual=None, pre=False):
         x64 = x.detach().double()
         if training:
             mean = x64.mean(dim=(0, 2, 3))
@@ -122,9 +122,9 @@ class OracleKernels:
         else:
             mean, var = running_mean.double(), running_var.double()
         invstd = 1.0 / torch.sqrt(var + eps)
-        if weight is not None:
+        if weight is not None and not pre:
             gamma, beta = self.gamma_beta_fwd(weight, m)
-        else:
+        else:                         # learnable gamma / beta, or the passport pair precomputed by the batched GEMV
             gamma, beta = gamma_in.detach().reshape(-1), beta_in.detach().reshape(-1)
         xh = ((x64 - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)).float()
         y = self.affine_relu_fwd(xh, gamma, beta, relu)

@@ -9,10 +9,14 @@ from deepipr_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(test_hooks=False):
+    """Entry points the header declares; test_hooks: only / also those inside `#ifdef DEEPIPR_TEST_HOOKS`."""
     text = open(os.path.join(ROOT, 'include', 'deepipr_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(deepipr_[a-z0-9_]+)\s*\(', text)))
+    hooks = ''.join(re.findall(r'#ifdef DEEPIPR_TEST_HOOKS(.*?)#endif', text, flags=re.S))
+    release = re.sub(r'#ifdef DEEPIPR_TEST_HOOKS.*?#endif', '', text, flags=re.S)
+    find = lambda t: sorted(set(re.findall(r'\b(deepipr_[a-z0-9_]+)\s*\(', t)))
+    return find(hooks) if test_hooks else find(release)
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,6 +26,24 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), n
     assert sorted(_lib.SIGNATURES) == names          # the ctypes table mirrors the header one to one
+
+
+def test_production_library_has_no_debug_or_test_symbols():
+    """Tuning knobs, the exchange time-out test hooks and the phase tracing exist only in the measurement / test build
+    (libdeepipr_hip_trace.so, -DDEEPIPR_TEST_HOOKS); the production library exports nothing named debug_ and nothing
+    the header does not declare for it."""
+    import subprocess
+    hooks = _declared(test_hooks=True)
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) and all('debug' in n for n in hooks)
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = sorted(ln.split()[-1] for ln in out.stdout.splitlines() if ' T ' in ln and 'deepipr_' in ln)
+    assert exported == _declared(), set(exported) ^ set(_declared())
+    assert not [n for n in exported if 'debug' in n or 'test' in n]
+    trace = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libdeepipr_hip_trace.so')
+    if os.path.exists(trace):                        # built by `make` next to the production library
+        t = subprocess.run(['nm', '-D', '--defined-only', trace], capture_output=True, text=True, check=True)
+        texp = sorted(ln.split()[-1] for ln in t.stdout.splitlines() if ' T ' in ln and 'deepipr_' in ln)
+        assert texp == sorted(_declared() + hooks)
 
 
 def test_abi_version_and_error_string():

@@ -599,14 +599,12 @@ def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
     """The residual-tail fusion (default; DEEPIPR_TAIL_FUSION=0 switches it off) against the separate tail kernels on whole nets, MIOpen
     pinned to its deterministic algorithms: logits and every parameter gradient bit-identical.
 
-    The two forms are deterministic functions of their inputs, so ONE bit-identical pair of steps proves that they round
-    alike; a pair that differs proves nothing while anything else in the step is not run-to-run reproducible.  That has
-    been seen once: 1 mismatch in 7 runs of the whole GPU suite (this test runs last in a ~10 minute session), against
-    0 in 2 440 steps of tools/determinism_probe.py in fresh processes -- also with every workspace of the python layer
-    pre-filled with NaN, and after find-mode steps in the same process (profiles/r02_determinism.md).  So a mismatch is
-    retried (at most twice) with a same-setting repeat beside it, reported as a warning naming what differed, and fails
-    only if no attempt is bit-identical."""
-    import warnings
+    No retry: a mismatch fails.  (Round 2 saw ONE mismatch in seven runs of the whole GPU suite and never reproduced it
+    -- 0 in 2 440 fresh-process steps; round 3: 0 in every session-end run of tests/test_zz_session_end_gpu.py, which
+    repeats this pair 2 x 40 times in the state a full session leaves behind and LOCALISES a mismatch instead of retrying
+    (first differing module in each direction, same-form repeat, kernel lists), and 0 differing results in 17 600
+    repeated vendor-convolution calls of the nets' shapes in pinned mode, tools/conv_determinism.py;
+    profiles/r03_determinism.md.)"""
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
@@ -637,20 +635,10 @@ def test_tail_fusion_is_bit_identical_at_model_level(private, monkeypatch):
             assert set(a) == set(b)
             return {k: float((a[k] - b[k]).abs().max()) for k in a if not torch.equal(a[k], b[k])}
 
-        notes = []
-        for attempt in range(3):
-            separate, fused = step('0'), step('1')
-            diff = differing(separate, fused)
-            if not diff:
-                break
-            repeat = differing(fused, step('1'))
-            notes.append('attempt %d: %d of %d tensors differ between the two forms (largest %s); the same form run '
-                         'twice differs on %d tensors' % (attempt, len(diff), len(fused),
-                                                         sorted(diff.items(), key=lambda kv: -kv[1])[:4], len(repeat)))
-        else:
-            pytest.fail('tail fusion never bit-identical in 3 attempts: ' + ' | '.join(notes))
-        if notes:
-            warnings.warn('tail fusion bit-identical only on attempt %d: %s' % (attempt, ' | '.join(notes)))
+        separate, fused = step('0'), step('1')
+        diff = differing(separate, fused)
+        assert not diff, ('%d of %d tensors differ between the fused and the separate tail (largest: %s)'
+                          % (len(diff), len(fused), sorted(diff.items(), key=lambda kv: -kv[1])[:4]))
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
 
@@ -1079,7 +1067,9 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
                 g = StagedStep(train_step_v1, prod, opt, x, y, graph=True, warmup=0)
                 plan = g.describe()
                 assert [s['cut'] for s in plan['stages']] == ['layer4.1', 'layer4.0', 'layer3.0', None], plan
-                assert [s['split_channel_kernels'] for s in plan['stages']] == [False, False, False, True], plan
+                # (stage 0 holds the forward pass, whose stem / layer1 / layer2 launches are split-channel -- harmless:
+                # nothing is in flight before it; of the backward stages only the last one has them)
+                assert [s['split_channel_kernels'] for s in plan['stages']][1:] == [False, False, True], plan
                 assert opt._mode == 'staged' and len(g._graphs) == 4
                 for i in range(3):
                     g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))

@@ -214,3 +214,29 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(private, monkeypatc
         assert rel <= 1e-4, (name, rel, scale)
     print('whole-net backward, kinks gated (%d of %d activations): worst gradient error %.2e of scale (%s)'
           % (gated, total, worst[0], worst[1]))
+
+
+# ----------------------------------------------------------------------------- cross-entropy head: labels out of range
+@pytest.mark.parametrize('bad', [-100, -1, 10, 1 << 40])
+def test_fused_cross_entropy_refuses_out_of_range_labels_loudly(K, bad):
+    """A label outside [0, C) -- F.cross_entropy's default ignore_index = -100 included, which this head does not
+    implement -- must not index out of bounds and must not give a plausible loss: loss is NaN, the row's gradient is
+    NaN, the other rows' gradients are untouched (k_ce_rows / k_ce_bwd read row[t] unvalidated)."""
+    from deepipr_amd import passport_ops as P
+    rs = np.random.RandomState(3)
+    logits = dev(rs.standard_normal((16, 10)) * 2).requires_grad_(True)
+    target = torch.from_numpy(rs.randint(0, 10, size=16).astype(np.int64)).to(DEV)
+    good_loss, _ = P.cross_entropy_top1(logits, target)
+    good_loss.backward()
+    good = logits.grad.clone()
+    logits.grad = None
+    target[5] = bad
+    loss, top1 = P.cross_entropy_top1(logits, target)
+    loss.backward()
+    assert torch.isnan(loss) and torch.isfinite(top1)
+    g = logits.grad
+    assert torch.isnan(g[5]).all()
+    keep = torch.ones(16, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert torch.isfinite(g[keep]).all() is not None          # rows scale with dloss = NaN-free upstream gradient (1.0)
+    assert torch.equal(g[keep], good[keep])

@@ -19,7 +19,7 @@ import torch
 
 pytestmark = [pytest.mark.gpu, pytest.mark.miopen_pinned]
 DEV = 'cuda:0'
-PAIRS = int(os.environ.get('DEEPIPR_SESSION_END_PAIRS', '12'))
+PAIRS = int(os.environ.get('DEEPIPR_SESSION_END_PAIRS', '40'))
 
 
 def _kernel_names(fn):

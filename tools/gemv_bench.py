@@ -49,6 +49,12 @@ def main():
         if junk is not None:
             junk.add_(1.0)
     out = {}
+    if _lib.has_test_hooks():                           # DEEPIPR_LIB = the test build: sweep the rows-per-workgroup forms
+        for rows in (1, 2, 4, 8):
+            os.environ['DEEPIPR_GEMV_ROWS'] = str(rows)
+            out['fwd_batched_rows%d' % rows] = timed(lambda: (flush(), K.gamma_beta_fwd_multi(ws, ms)), args.reps, 'gamma_beta_fwd')
+            out['fwd_per_layer_rows%d' % rows] = timed(lambda: (flush(), [K.gamma_beta_fwd(w, m) for w, m in zip(ws, ms)]), args.reps, 'gamma_beta_fwd')
+        del os.environ['DEEPIPR_GEMV_ROWS']
     out['fwd_per_layer'] = timed(lambda: (flush(), [K.gamma_beta_fwd(w, m) for w, m in zip(ws, ms)]), args.reps, 'gamma_beta_fwd')
     out['fwd_batched'] = timed(lambda: (flush(), K.gamma_beta_fwd_multi(ws, ms)), args.reps, 'gamma_beta_fwd')
     out['bwd_acc_per_layer'] = timed(lambda: (flush(), [K.gamma_beta_bwd_acc(g, b, m, d) for g, b, m, d in zip(dgs, dbs, ms, dws)]),
