@@ -427,91 +427,6 @@ __global__ __launch_bounds__(kThreads) void k_gamma_beta_multi(GemvBatch B) {
     }
 }
 
-// The same GEMV with the pooled vectors staged through LDS: in the register form above every workgroup pulls both f64
-// vectors (16 B per float of a row: 4x the row's own bytes) from L2 for only RPW rows -- 1 280 workgroups x 73 KB =
-// 94 MB of L2 reads next to 33.6 MB of HBM reads for ResNet18's layer4, which measured L2-bound (11.6 us, 0.36 of HBM
-// peak).  Here a workgroup owns 2*RP rows and walks K in chunks of kGemvChunk float4 (two trips of the 256 threads):
-// the chunk of both vectors goes to LDS once (32 KB), every row of the workgroup reads it from there.  Thread t still
-// owns the float4 positions q = t (mod 256) in ascending order and the workgroup combine is the same
-// (wave butterfly, then (w0 + w1) + (w2 + w3)): results are BIT-IDENTICAL to the register form.
-constexpr int kGemvChunk = 2 * kThreads;           // float4 per chunk of K
-
-template <int RP>
-__global__ __launch_bounds__(kThreads) void k_gamma_beta_multi_lds(GemvBatch B) {
-    __shared__ __attribute__((aligned(16))) double sm[2][kGemvChunk * 4];      // [scale | bias][chunk], 32 KB
-    __shared__ double red[RP * 2][2][kThreads / kWave];
-    int li = 0;
-    for (int i = 1; i < B.n; ++i)
-        if (static_cast<int>(blockIdx.x) >= B.L[i].block0) li = i;
-    const float *W = B.L[li].W;
-    const double *m = B.L[li].m;
-    const int Co = B.L[li].Co, K = B.L[li].K;
-    const int co0 = (static_cast<int>(blockIdx.x) - B.L[li].block0) * (2 * RP);
-    const int K4 = K / 4;
-    const int t = threadIdx.x;
-    double acc[RP * 2][2];
-    const float4 *row[RP * 2];
-#pragma unroll
-    for (int r = 0; r < RP * 2; ++r) {
-        acc[r][0] = 0.0;
-        acc[r][1] = 0.0;
-        row[r] = reinterpret_cast<const float4 *>(W + static_cast<size_t>(min(co0 + r, Co - 1)) * K);
-    }
-    for (int base = 0; base < K4; base += kGemvChunk) {
-        const int n4 = min(kGemvChunk, K4 - base);          // float4 positions in this chunk
-        float4 w[RP * 2][2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + t;
-#pragma unroll
-            for (int r = 0; r < RP * 2; ++r)
-                w[r][p] = q < n4 ? row[r][base + q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        __syncthreads();                                     // the previous chunk's readers are done
-        for (int i = t; i < 2 * n4; i += kThreads) {          // double2 units of the two vectors' chunks
-            reinterpret_cast<double2 *>(sm[0])[i] = reinterpret_cast<const double2 *>(m + 4 * static_cast<size_t>(base))[i];
-            reinterpret_cast<double2 *>(sm[1])[i] = reinterpret_cast<const double2 *>(m + K + 4 * static_cast<size_t>(base))[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + t;
-            if (q < n4) {
-                const double2 s0 = reinterpret_cast<const double2 *>(sm[0])[2 * q];
-                const double2 s1 = reinterpret_cast<const double2 *>(sm[0])[2 * q + 1];
-                const double2 b0 = reinterpret_cast<const double2 *>(sm[1])[2 * q];
-                const double2 b1 = reinterpret_cast<const double2 *>(sm[1])[2 * q + 1];
-#pragma unroll
-                for (int r = 0; r < RP * 2; ++r) {
-                    acc[r][0] = fma(static_cast<double>(w[r][p].x), s0.x, acc[r][0]);
-                    acc[r][0] = fma(static_cast<double>(w[r][p].y), s0.y, acc[r][0]);
-                    acc[r][0] = fma(static_cast<double>(w[r][p].z), s1.x, acc[r][0]);
-                    acc[r][0] = fma(static_cast<double>(w[r][p].w), s1.y, acc[r][0]);
-                    acc[r][1] = fma(static_cast<double>(w[r][p].x), b0.x, acc[r][1]);
-                    acc[r][1] = fma(static_cast<double>(w[r][p].y), b0.y, acc[r][1]);
-                    acc[r][1] = fma(static_cast<double>(w[r][p].z), b1.x, acc[r][1]);
-                    acc[r][1] = fma(static_cast<double>(w[r][p].w), b1.y, acc[r][1]);
-                }
-            }
-        }
-    }
-    const int wave = t >> 6, lane = t & 63;
-#pragma unroll
-    for (int r = 0; r < RP * 2; ++r) {
-        const double a = wave_sum(acc[r][0]), b = wave_sum(acc[r][1]);
-        if (lane == 0) {
-            red[r][0][wave] = a;
-            red[r][1][wave] = b;
-        }
-    }
-    __syncthreads();
-    if (t < RP * 2 * 2) {
-        const int r = t >> 1, which = t & 1;
-        const double v = (red[r][which][0] + red[r][which][1]) + (red[r][which][2] + red[r][which][3]);
-        if (co0 + r < Co) (which ? B.L[li].beta : B.L[li].gamma)[co0 + r] = static_cast<float>(v);
-    }
-}
-
 // The rank-2 update dW[co, :] (+)= dgamma[co] * m_scale + dbeta[co] * m_bias of several layers in one launch, the
 // accumulate form with all of a thread's loads of dW in flight before the first store.
 struct Rank2Layer {
@@ -2642,28 +2557,21 @@ int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *st
     if (!layers || n <= 0 || n > kGemvMaxLayers)
         return fail(DEEPIPR_EINVAL, "gamma_beta_fwd_multi: 1..%d layers per call", kGemvMaxLayers);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    long long rows = 0;
     double bytes = 0.0;
     for (int i = 0; i < n; ++i) {
         const DeepiprGemvLayer &l = layers[i];
         if (!l.W || !l.m || !l.gamma || !l.beta || l.Co <= 0 || l.K <= 0)
             return fail(DEEPIPR_EINVAL, "gamma_beta_fwd_multi: bad layer %d", i);
-        rows += l.Co;
         bytes += 4.0 * static_cast<double>(l.Co) * l.K;
     }
-    const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
-    bool all_vec = true;
-    for (int i = 0; i < n; ++i)
-        all_vec = all_vec && layers[i].K % 4 == 0 && aligned16(layers[i].W) && aligned16(layers[i].m);
-    // rows per workgroup: LDS form (every layer 16-byte aligned with K % 4 == 0) 8 rows once that leaves >= 2
-    // workgroups per CU, else 4; register form (odd K) 2 rows once that leaves >= 4 workgroups per CU, else 1
-    int rows_per_wg;
-    if (all_vec) rows_per_wg = rows >= 16ll * cus ? 8 : 4;
-    else rows_per_wg = rows >= 8ll * cus ? 2 : 1;
+    // One row of W per workgroup.  Measured on the five layer4 weights of ResNet18 (33.6 MB, tools/gemv_bench.py with the
+    // test build's DEEPIPR_GEMV_ROWS, profiles/r03_gemv_sweep.json): 1 row 10.6 us, 2 rows sharing the pooled vectors
+    // 11.4 us, and a form that staged the pooled vectors through LDS for 4 / 8 rows 13.7 / 19.0 us -- the launch is
+    // bound by memory-level parallelism (workgroups in flight), not by the L2 traffic of the pooled vectors.
+    int rows_per_wg = 1;
 #ifdef DEEPIPR_TEST_HOOKS
-    if (const char *e = getenv("DEEPIPR_GEMV_ROWS")) {      // tuning (tools/gemv_bench.py): 1 / 2 = register form, 4 / 8 = LDS form
-        const int v = atoi(e);
-        if ((v == 1 || v == 2) || ((v == 4 || v == 8) && all_vec)) rows_per_wg = v;
+    if (const char *e = getenv("DEEPIPR_GEMV_ROWS")) {      // tuning (tools/gemv_bench.py)
+        if (atoi(e) == 2) rows_per_wg = 2;
     }
 #endif
     GemvBatch B{};
@@ -2677,12 +2585,8 @@ int deepipr_gamma_beta_fwd_multi(const DeepiprGemvLayer *layers, int n, void *st
     }
     ProfScope prof(DEEPIPR_K_GAMMA_BETA_FWD, st);
     prof.bytes = bytes;
-    switch (rows_per_wg) {
-        case 8: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi_lds<4>), dim3(blocks), dim3(kThreads), st, B); break;
-        case 4: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi_lds<2>), dim3(blocks), dim3(kThreads), st, B); break;
-        case 2: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<2>), dim3(blocks), dim3(kThreads), st, B); break;
-        default: DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<1>), dim3(blocks), dim3(kThreads), st, B); break;
-    }
+    if (rows_per_wg == 2) DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<2>), dim3(blocks), dim3(kThreads), st, B);
+    else DEEPIPR_LAUNCH(prof, (k_gamma_beta_multi<1>), dim3(blocks), dim3(kThreads), st, B);
     return check_launch("gamma_beta_fwd");
 }
 

@@ -14,7 +14,7 @@ def alexnet_config(l4=True, l5=True, l6=True):
     return {'0': False, '2': False, '4': l4, '5': l5, '6': l6}
 
 
-def resnet18_config(layer4=True):
+def resnet18_config(layer4=True, blocks=2):
     def blk(flag, shortcut):
         d = {'convbnrelu_1': flag, 'convbn_2': flag}
         if shortcut:
@@ -23,8 +23,15 @@ def resnet18_config(layer4=True):
     cfg = {'convbnrelu_1': False}
     for li in (1, 2, 3, 4):
         flag = layer4 if li == 4 else False
-        cfg['layer%d' % li] = {'0': blk(flag, li != 1), '1': blk(flag, False)}
+        cfg['layer%d' % li] = {'0': blk(flag, li != 1)}
+        if blocks > 1:
+            cfg['layer%d' % li]['1'] = blk(flag, False)
     return cfg
+
+
+def resnet9_config(layer4=True):
+    """passport_configs/resnet9_passport.json: one BasicBlock per layer (models/resnet_passport.py:187-188)."""
+    return resnet18_config(layer4, blocks=1)
 
 
 SGD = dict(lr=0.01, momentum=0.9, weight_decay=1e-4)   # experiments/classification.py:47-50
@@ -60,6 +67,12 @@ CASES = {
                                 key_type='shuffle', nkeys=4),
     'alexnet_v1_shuffle': dict(arch='alexnet', scheme=1, norm='bn', ncls=10, n=4, config=alexnet_config(),
                                key_type='shuffle', nkeys=5),
+    # --key-type image (train_v1.py:30): ONE passport image per key, pushed through the plain net; set_key keeps a
+    # batch-1 key as it is (passportconv2d.py:125-137: no passport_selection), passport_generator.py:30-43
+    'resnet18_v1_image': dict(arch='resnet18', scheme=1, norm='bn', ncls=10, n=4, config=resnet18_config(),
+                              key_type='image', nkeys=1),
+    # ResNet9 (--arch resnet9, models/resnet_passport.py:187-188: BasicPassportBlock x [1, 1, 1, 1])
+    'resnet9_v1':    dict(arch='resnet9', scheme=1, norm='bn', ncls=10, n=4, config=resnet9_config()),
 }
 
 ALPHA = 0.1                                             # train_v1.py:33 --sign-loss default

@@ -344,6 +344,8 @@ def plain_net(arch, num_classes, norm_type='bn'):
     kw = {'convbnrelu_1': off}
     for li in (1, 2, 3, 4):
         kw['layer%d' % li] = {'0': blk, '1': blk}
+    if arch == 'resnet9':
+        return resnet9_ref(num_classes=num_classes, passport_kwargs=kw)
     return resnet18_ref(num_classes=num_classes, passport_kwargs=kw)
 
 

@@ -22,6 +22,8 @@ class OracleImpl:
         private = case['scheme'] != 1
         if case['arch'] == 'alexnet':
             return torch_ref.AlexNetRef(3, case['ncls'], kw, private=private)
+        if case['arch'] == 'resnet9':
+            return torch_ref.resnet9_ref(num_classes=case['ncls'], passport_kwargs=kw, private=private)
         return torch_ref.resnet18_ref(num_classes=case['ncls'], passport_kwargs=kw, private=private)
 
     def plain(self, case):
@@ -60,13 +62,15 @@ class ProductImpl:
         from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
         from deepipr_amd.models.alexnet_passport import AlexNetPassport
         from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
-        from deepipr_amd.models.resnet_passport import ResNet18Passport
+        from deepipr_amd.models.resnet_passport import ResNet9Passport, ResNet18Passport
         from deepipr_amd.models.resnet_passport_private import ResNet18Private
         kw = construct_passport_kwargs_from_dict({'passport_config': case['config'], 'norm_type': case['norm'],
                                                   'key_type': case.get('key_type', 'random'), 'sl_ratio': ALPHA})
         private = case['scheme'] != 1
         if case['arch'] == 'alexnet':
             model = (AlexNetPassportPrivate if private else AlexNetPassport)(3, case['ncls'], kw)
+        elif case['arch'] == 'resnet9':
+            model = ResNet9Passport(num_classes=case['ncls'], passport_kwargs=kw)
         else:
             model = (ResNet18Private if private else ResNet18Passport)(num_classes=case['ncls'], passport_kwargs=kw)
         for m in model.modules():
@@ -76,9 +80,11 @@ class ProductImpl:
 
     def plain(self, case):
         from deepipr_amd.models.alexnet_normal import AlexNetNormal
-        from deepipr_amd.models.resnet_normal import ResNet18
+        from deepipr_amd.models.resnet_normal import ResNet9, ResNet18
         if case['arch'] == 'alexnet':
             return AlexNetNormal(3, case['ncls'], case['norm']).to(self.device)
+        if case['arch'] == 'resnet9':
+            return ResNet9(num_classes=case['ncls'], norm_type=case['norm']).to(self.device)
         return ResNet18(num_classes=case['ncls'], norm_type=case['norm']).to(self.device)
 
     def set_keys(self, plain, model, kx, ky):

@@ -41,8 +41,8 @@ from models.alexnet_passport import AlexNetPassport                  # noqa: E40
 from models.alexnet_passport_private import AlexNetPassportPrivate   # noqa: E402
 from models.layers.passportconv2d import PassportBlock               # noqa: E402
 from models.layers.passportconv2d_private import PassportPrivateBlock  # noqa: E402
-from models.resnet_normal import ResNet18                            # noqa: E402
-from models.resnet_passport import ResNet18Passport                  # noqa: E402
+from models.resnet_normal import ResNet9, ResNet18                   # noqa: E402
+from models.resnet_passport import ResNet9Passport, ResNet18Passport  # noqa: E402
 from models.resnet_passport_private import ResNet18Private           # noqa: E402
 
 from oracle import runner                                            # noqa: E402
@@ -61,6 +61,9 @@ class ReferenceImpl:
         if case['arch'] == 'alexnet':
             cls = AlexNetPassportPrivate if private else AlexNetPassport
             return cls(3, case['ncls'], kw)
+        if case['arch'] == 'resnet9':
+            assert not private
+            return ResNet9Passport(num_classes=case['ncls'], passport_kwargs=kw)
         cls = ResNet18Private if private else ResNet18Passport
         return cls(num_classes=case['ncls'], passport_kwargs=kw)
 
@@ -68,6 +71,8 @@ class ReferenceImpl:
         """The key-propagation net of --key-type shuffle (experiments/classification.py:68-100)."""
         if case['arch'] == 'alexnet':
             return AlexNetNormal(3, case['ncls'], case['norm'])
+        if case['arch'] == 'resnet9':
+            return ResNet9(num_classes=case['ncls'], norm_type=case['norm'])
         return ResNet18(num_classes=case['ncls'], norm_type=case['norm'])
 
     def set_keys(self, plain, model, kx, ky):

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--private', action='store_true')
     ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--only', default='', help='run one variant only (for a rocprofv3 trace): graph1 | staged-N[-noxchg]')
     a = ap.parse_args()
     rank, local, world = D.init_from_env()
     dev = torch.device('cuda', local)
@@ -64,10 +65,11 @@ def main():
         t2 = time.perf_counter()
         out[name] = {'host_enqueue_ms': round(1000 * (t1 - t0) / a.steps, 3), 'step_ms': round(1000 * (t2 - t0) / a.steps, 3)}
 
-    net, opt = fresh()
-    g1 = GraphedTrainStep(fn, net, opt, x, y, optimizer_in_graph=False)
-    measure('graph1', lambda: g1(x, y))
-    del g1, net, opt
+    if a.only in ('', 'graph1'):
+        net, opt = fresh()
+        g1 = GraphedTrainStep(fn, net, opt, x, y, optimizer_in_graph=False)
+        measure('graph1', lambda: g1(x, y))
+        del g1, net, opt
 
     real_plan = S.plan_stages
     for merge in (0, 1, 2):
@@ -79,6 +81,9 @@ def main():
             return st
         S.plan_stages = plan
         for noxchg in (False, True):
+            name = 'staged-%d%s' % (4 - merge, '-noxchg' if noxchg else '')
+            if a.only and a.only != name:
+                continue
             net, opt = fresh()
             st = S.StagedStep(fn, net, opt, x, y, graph=True)
             if noxchg:
