@@ -465,7 +465,12 @@ def main():
                  'bn_affine_fwd': 'norm+affine+ReLU forward apply pass (8 B/elt)',
                  'bn_bwd_reduce': 'backward channel sums (8 B/elt)', 'bn_stats': 'batch statistics (4 B/elt)',
                  'affine_bwd': 'affine backward: read dy + xhat, write dxhat (12 B/elt)',
-                 'affine_fwd': 'affine forward (8 B/elt)', 'sgd': 'fused SGD over the flat buffers (20 B/param)'}
+                 'affine_fwd': 'affine forward (8 B/elt)', 'sgd': 'fused SGD over the flat buffers (20 B/param)',
+                 # the kernel pair the north star names: gamma / beta of ALL passport layers in one launch (W read once,
+                 # 4 B/weight) and the rank-2 update accumulated into each layer's wgrad (8 B/weight, one launch per layer)
+                 'gamma_beta_fwd': 'passport GEMV, all passport layers in one launch: gamma, beta = W . pooled keys (4 B/weight)',
+                 'gamma_beta_bwd': 'passport rank-2 update accumulated into the conv wgrad (8 B/weight)'}
+    NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd')
     if out['exchange_timeouts']:
         out['roofline_refused'] = ('an in-launch exchange of the single-pass kernels timed out (%d buffer(s)): their '
                                    'outputs were poisoned; no roofline is reported for this run' % out['exchange_timeouts'])
@@ -484,13 +489,13 @@ def main():
                               'bytes_per_step': int(nbytes / sampled),
                               'GBps': round(nbytes / (ms * 1e-3) / 1e9, 1)}
                 kern[name]['frac'] = round(kern[name]['GBps'] / HBM_PEAK_GBS, 4)
-        for name in ('gamma_beta_fwd', 'gamma_beta_bwd', 'passport_bwd_finish', 'reduce_partials'):
+        for name in ('passport_bwd_finish', 'reduce_partials'):
             ms, n = prof.get(name, (0, 0))
             if n:
                 kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3),
                               'us_per_step': round(1000.0 * ms / sampled, 1)}
         # dominant kernel = the passport/norm streaming kernel with the most time per step
-        dom = max((k for k in kern if k in STREAMING and k != 'sgd'), key=lambda k: kern[k]['us_per_step'])
+        dom = max((k for k in kern if k in STREAMING and k not in NOT_DOMINANT), key=lambda k: kern[k]['us_per_step'])
         a = kern[dom]
         per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
         # PMC traffic: rocprofv3 --pmc passes over this very command (tools/gpu_pmc_in_situ.sh, summarised into
@@ -499,6 +504,9 @@ def main():
         out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
                            'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
                            'traffic': pmc_bytes,
+                           # PMC counters need their own rocprofv3 passes: the figure is the committed record of such
+                           # passes over this command, quoted only when this run's launch mix equals the recorded one
+                           'traffic_source': 'profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' if pmc_bytes else None,
                            'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
                            'launches_per_step': a['launches_per_step'],
                            'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '

@@ -67,6 +67,7 @@ SIGNATURES = {
                                        _vp, _f32p, _f32p, _f32p, _vp]),
     'deepipr_passport_bn_resident': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_bn_slices': (_int, [_int, _int, _int]),
+    'deepipr_passport_bn_passes': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_supported': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_gn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _flt, _int,
@@ -83,8 +84,8 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_trace': (_int, [_vp]),
 }
 ABI_VERSION = 5
-SYNC_WORDS = 2 * 256 * 30 * 4 + 16     # DEEPIPR_SYNC_WORDS
-SYNC_TIMEOUT_WORD = 2 * 256 * 30 * 4   # DEEPIPR_SYNC_TIMEOUT_WORD
+SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
+SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
 
 GEMV_MAX_LAYERS = 16                    # DEEPIPR_GEMV_MAX_LAYERS

@@ -1487,18 +1487,23 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 // Fixed-order sums throughout: bit-reproducible run to run.
 // ============================================================================================
 // Exchange buffer (`sync`, DEEPIPR_SYNC_WORDS 32-bit words = granules of 8 bytes): for every slice count S in
-// {2, 4, 8, 16} a region of kXchChannels x S slots of 4 granules; then the time-out word.
+// {2, 4, 8, 16} a region of kXchChannels x S slots of 4 granules, for S in {32, 64} (maps too large for one pass, see
+// plan_resident) a region of 1024 granules each; then the time-out word.  A slot is addressed by the channel's index
+// WITHIN the launch (a launch splits at most 256 / S channels), so channel-range passes of one layer reuse the slots.
 constexpr int kXchChannels = 256;                  // channels are split only when C < CUs, i.e. C <= 255
-constexpr int kXchMaxSlices = 16;                  // 4 granules per slice, one lane each: 64 lanes
-constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4;
+constexpr int kXchMaxSlices = 64;                  // 4 granules per slice: up to 256 granules, four per lane of wave 0
+constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4 + 2 * 1024;
 constexpr int kSyncTimeoutWord = 2 * kXchGranules;
+static_assert(kSyncTimeoutWord == DEEPIPR_SYNC_TIMEOUT_WORD && kSyncTimeoutWord + 16 == DEEPIPR_SYNC_WORDS, "header out of step");
 constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(2) + one poll: a few seconds
 
 struct ResPlan {
     int T, F4;            // threads per workgroup, float4 units per thread
     int S, nps;           // batch slices per channel group, samples per slice
     int G, q4, gq;        // channels per workgroup, float4 per plane, G*q4
-    int blocks;           // (C/G) * S
+    int blocks;           // workgroups of this launch: (channels of the pass / G) * S
+    int c_off;            // first channel of this launch (channel-range passes of a map too large for one pass)
+    int cpp, passes;      // host side: channels per pass, number of passes (1: the whole layer in one launch)
     FastDiv gqdiv;
 #ifdef DEEPIPR_TEST_HOOKS
     // Measurement / test build only (`make trace`: libdeepipr_hip_trace.so; the production library has none of this):
@@ -1590,7 +1595,10 @@ __device__ __forceinline__ unsigned long long xch_load(const unsigned long long 
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load ... sc1: bypasses L1
 }
 
-__device__ __forceinline__ int xch_region(int S) { return kXchChannels * (S - 2) * 4; }   // 2 + 4 + ... + S/2 = S - 2
+__device__ __forceinline__ int xch_region(int S) {
+    if (S <= 16) return kXchChannels * (S - 2) * 4;                         // 2 + 4 + ... + S/2 = S - 2
+    return kXchChannels * 30 * 4 + (S == 32 ? 0 : 1024);
+}
 
 // Called by every thread at kernel entry (only wave 0 needs it; one L2 round trip hidden behind the bulk loads).
 __device__ __forceinline__ ResXch res_xch_begin(unsigned *sync, int c, int s, int S) {
@@ -1612,27 +1620,41 @@ __device__ __forceinline__ void res_exchange(double &s0, double &s1, const ResXc
         __hip_atomic_store(x.gran + s * 4 + lane, (static_cast<unsigned long long>(x.expect) << 32) | half,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ONE 8-byte sc1 store
     }
-    unsigned long long v = 0;
-    bool ok = lane >= 4 * S;
+    // lane i polls granules i, i + 64, i + 128, i + 192 (S <= 16: the first one only)
+    constexpr int kRounds = kXchMaxSlices * 4 / kWave;
+    unsigned long long v[kRounds];
+    bool ok[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        v[r] = 0;
+        ok[r] = lane + r * kWave >= 4 * S;
+    }
     bool expired = false;
     unsigned spins = 0;
     while (true) {
-        if (!ok) {
-            v = xch_load(x.gran + lane);
-            ok = static_cast<unsigned>(v >> 32) == x.expect;
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            if (!ok[r]) {
+                v[r] = xch_load(x.gran + lane + r * kWave);
+                ok[r] = static_cast<unsigned>(v[r] >> 32) == x.expect;
+            }
+            all = all && ok[r];
         }
-        if (__all(ok)) break;
+        if (__all(all)) break;
         __builtin_amdgcn_s_sleep(2);
         if (++spins > spin_limit) {
             expired = true;
             break;
         }
     }
-    const unsigned pay = static_cast<unsigned>(v);
     double t0 = 0.0, t1 = 0.0;
     for (int sp = 0; sp < S; ++sp) {                   // slice order: identical rounding in every partner
-        const unsigned long long lo0 = __shfl(pay, 4 * sp, kWave), hi0 = __shfl(pay, 4 * sp + 1, kWave);
-        const unsigned long long lo1 = __shfl(pay, 4 * sp + 2, kWave), hi1 = __shfl(pay, 4 * sp + 3, kWave);
+        const int r = sp >> 4;                          // granule 4 * sp + j sits in round (4 * sp + j) / 64 = sp / 16
+        const unsigned pay = static_cast<unsigned>(r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3]);
+        const int g = (4 * sp) & (kWave - 1);
+        const unsigned long long lo0 = __shfl(pay, g, kWave), hi0 = __shfl(pay, g + 1, kWave);
+        const unsigned long long lo1 = __shfl(pay, g + 2, kWave), hi1 = __shfl(pay, g + 3, kWave);
         t0 += __longlong_as_double(static_cast<long long>((hi0 << 32) | lo0));
         t1 += __longlong_as_double(static_cast<long long>((hi1 << 32) | lo1));
     }
@@ -1703,12 +1725,12 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     const int t = threadIdx.x;
     int cb, s;
     res_block_coords(pl, cb, s);
-    const int c0 = cb * pl.G;
+    const int c0 = pl.c_off + cb * pl.G;
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
     ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, c0, s, pl.S);
+    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);              // slot = the channel's index within this launch
     // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
     res_stamp(pl, 0);
     // what the channel table needs besides the sums, loaded up front
@@ -1845,12 +1867,12 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
     const int t = threadIdx.x;
     int cb, s;
     res_block_coords(pl, cb, s);
-    const int c0 = cb * pl.G;
+    const int c0 = pl.c_off + cb * pl.G;
     const int n0 = s * pl.nps;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
     ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, c0, s, pl.S);
+    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);
     res_stamp(pl, 0);
     const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
     float4 dz[F4], xh[F4];
@@ -2879,7 +2901,41 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
             pl.F4 = f;
             break;
         }
-    if (pl.F4 == 0) return false;
+    pl.c_off = 0;
+    pl.cpp = C;
+    pl.passes = 1;
+    if (pl.F4 == 0) {
+        // The layer does not fit the register file at once (ImageNet-size maps: [128, 64, 112, 112] is 411 MB against
+        // 67 MB of registers a forward / 33 MB per tensor a backward launch can hold).  Channel-range PASSES: a launch
+        // takes as many channels as fill the chip once each is split over S workgroups, S the smallest power of two for
+        // which a slice fits a workgroup's registers; the layer is ceil(C / channels per pass) launches of the same
+        // single-pass kernel -- x is still read once and y written once (8 / 12 B per element instead of the 12 / 20 of
+        // the three-launch form), at the price of an in-launch exchange among up to 64 partners.
+        if (!can_sync || G != 1) return false;
+        const int lim = cus < kXchChannels ? cus : kXchChannels;
+        bool found = false;
+        for (int Sp = 2; Sp <= kXchMaxSlices && Sp <= N && Sp <= lim; Sp *= 2) {
+            const long long nps = (N + Sp - 1) / Sp;
+            const long long nd = (nps * pl.q4 + 1023) / 1024;
+            int f4 = 0;
+            for (int f : steps)
+                if (f >= nd && f <= max_f4) {
+                    f4 = f;
+                    break;
+                }
+            if (!f4) continue;
+            pl.S = Sp;
+            pl.nps = static_cast<int>(nps);
+            pl.T = 1024;
+            pl.F4 = f4;
+            pl.cpp = lim / Sp < C ? lim / Sp : C;
+            pl.passes = (C + pl.cpp - 1) / pl.cpp;
+            pl.blocks = pl.cpp * Sp;
+            found = true;
+            break;
+        }
+        if (!found) return false;
+    }
     pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
 #ifdef DEEPIPR_TEST_HOOKS
     pl.spin = static_cast<unsigned>(g_tune.spin.load(std::memory_order_relaxed));
@@ -2905,7 +2961,7 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
                    const ResPlan &pl, const BnFinishArgs &f, double *part, unsigned *sync, bool with_sign,
                    const SignArgs &sa, const float *residual, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
-    prof.bytes = (residual ? 12.0 : 8.0) * static_cast<double>(N) * C * pl.q4 * 4;
+    prof.bytes = (residual ? 12.0 : 8.0) * static_cast<double>(N) * (pl.blocks / pl.S * pl.G) * pl.q4 * 4;
     const float4 *r4 = reinterpret_cast<const float4 *>(residual);
     const dim3 grid(pl.blocks + (with_sign ? 1 : 0));
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -2926,7 +2982,8 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
 int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
                    const ResPlan &pl, double *part, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
-    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : (a.dy2 ? 16.0 : 12.0)) * static_cast<double>(N) * C * pl.q4 * 4;
+    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : (a.dy2 ? 16.0 : 12.0)) * static_cast<double>(N) *
+                 (pl.blocks / pl.S * pl.G) * pl.q4 * 4;
     const dim3 grid(pl.blocks);
     const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *o4 = reinterpret_cast<float4 *>(dx);
@@ -2992,6 +3049,12 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
     if (plan_resident(N, C, HW, 16, have_sync != 0, &rp)) mask |= 1;
     if (plan_resident(N, C, HW, 8, have_sync != 0, &rp)) mask |= 2;
     return mask;
+}
+
+int deepipr_passport_bn_passes(int N, int C, int HW, int backward) {
+    if (bad_dims(N, C, HW)) return 0;
+    ResPlan rp;
+    return plan_resident(N, C, HW, backward ? 8 : 16, true, &rp) ? rp.passes : 0;
 }
 
 int deepipr_passport_bn_slices(int N, int C, int HW) {
@@ -3075,7 +3138,17 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
         f.part = part;
         f.NS = rp.S;
         SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
-        return launch_res_fwd(x, y, g, bt, relu, N, C, rp, f, part, sync, with_sign, sa, residual, st);
+        for (int p = 0; p < rp.passes; ++p) {              // one launch, or channel-range passes of a large map
+            ResPlan q = rp;
+            q.c_off = p * rp.cpp;
+            const int cn = C - q.c_off < rp.cpp ? C - q.c_off : rp.cpp;
+            q.blocks = (cn / q.G) * q.S;
+            BnFinishArgs fp = f;
+            if (p) fp.num_batches_tracked = nullptr;       // counted once per call
+            int rc = launch_res_fwd(x, y, g, bt, relu, N, C, q, fp, part, sync, with_sign && p == 0, sa, residual, st);
+            if (rc != DEEPIPR_OK) return rc;
+        }
+        return DEEPIPR_OK;
     }
     if (residual)
         return fail(DEEPIPR_EUNSUPPORTED, "passport_bn_fwd: the fused residual tail needs the single-pass form "
@@ -3173,8 +3246,14 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                      training ? 1.0 / (static_cast<double>(N) * HW) : 0.0,
                      reinterpret_cast<const float4 *>(dy2), reinterpret_cast<const float4 *>(tail_out),
                      reinterpret_cast<float4 *>(dres)};
-        int rc = launch_res_bwd(dy, x, table, dx, relu, N, C, rp, part, sync, a, st);
-        if (rc != DEEPIPR_OK) return rc;
+        for (int p = 0; p < rp.passes; ++p) {
+            ResPlan q = rp;
+            q.c_off = p * rp.cpp;
+            const int cn = C - q.c_off < rp.cpp ? C - q.c_off : rp.cpp;
+            q.blocks = (cn / q.G) * q.S;
+            int rc = launch_res_bwd(dy, x, table, dx, relu, N, C, q, part, sync, a, st);
+            if (rc != DEEPIPR_OK) return rc;
+        }
         return dW ? deepipr_gamma_beta_bwd(dgamma, dbeta, m, C, K, dW, stream) : DEEPIPR_OK;
     }
     if (tail_out || dy2)

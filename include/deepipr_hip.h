@@ -216,7 +216,8 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * concurrently.  That form needs all its workgroups co-resident, so pass
  * sync == NULL whenever another kernel may occupy CUs of the device at the same time (e.g. a collective on a
  * second stream); channel-owning layers (C >= CUs) then still take the single pass, the others the 3-launch
- * form.  If a bounded in-kernel wait ever expires, word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero AND the
+ * form.  Maps too large for the register file at once run as channel-range passes of the same kernels
+ * (deepipr_passport_bn_passes).  If a bounded in-kernel wait ever expires, word [DEEPIPR_SYNC_TIMEOUT_WORD] becomes non-zero AND the
  * affected channels' statistics are poisoned with NaN (so y / dx, the loss and every gradient turn NaN): the
  * failure cannot pass silently.  The host layer checks the word once per epoch and raises.
  * deepipr_set_resident(0) disables the single-pass kernels process-wide (testing), (1) restores the default.
@@ -232,8 +233,8 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * kernel (16 B/element) instead of by a separate add pass.  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
  * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
  * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
-#define DEEPIPR_SYNC_WORDS (2 * 256 * 30 * 4 + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, + flags */
-#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * 256 * 30 * 4)
+#define DEEPIPR_SYNC_WORDS (2 * (256 * 30 * 4 + 2048) + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, 2 x 1024 for 32 / 64 slices, + flags */
+#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * (256 * 30 * 4 + 2048))
 int deepipr_set_resident(int mode);
 #ifdef DEEPIPR_TEST_HOOKS
 /* MEASUREMENT / TEST BUILD ONLY (libdeepipr_hip_trace.so, `make -C deepipr_amd/csrc trace`): the production library
@@ -256,6 +257,11 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
  * only: lets a driver that overlaps collectives with compute know WHICH layer calls depend on co-residency
  * (deepipr_amd/experiments/staged.py keeps collectives away from exactly those stages). */
 int deepipr_passport_bn_slices(int N, int C, int HW);
+/* Launches the single-pass form takes for this shape when exchange words are passed: 1 = the whole layer in one
+ * launch; > 1 = channel-range passes of a map too large for the register file (ImageNet-size maps: each pass holds as
+ * many channels as fill the chip once every channel is split over up to 64 workgroups; still 8 / 12 B per element);
+ * 0 = not single-pass (three launches). */
+int deepipr_passport_bn_passes(int N, int C, int HW, int backward);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
                             const float *beta_in, const float *b, float alpha, float margin, float l2,

@@ -17,6 +17,7 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--top', type=int, default=25)
+    ap.add_argument('--gaps', type=int, default=0, help='also list the N largest idle gaps between consecutive kernels')
     ap.add_argument('--marker', default=None, help='once-per-step kernel (default: k_ce_finish, else nll_loss_forward)')
     args = ap.parse_args()
     rows = []
@@ -55,6 +56,27 @@ def main():
         print('| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.2f |' %
               (short, len(v) / args.steps, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3,
                sum(v) / args.steps / 1e3, 100.0 * sum(v) / busy))
+    if args.gaps:
+        gaps(win, args.steps, args.gaps)
+
+
+def gaps(win, steps, top):
+    """Idle time between consecutive kernels of the window (end of the latest-ending kernel so far -> next start)."""
+    out, end = [], win[0][1]
+    for (s, e, n), prev in zip(win[1:], win[:-1]):
+        if s > end:
+            out.append((s - end, prev[2], n))
+        end = max(end, e)
+    total = sum(g for g, _, _ in out)
+    print('\nidle between kernels: %.1f us per step in %d gaps per step; the largest:' %
+          (total / steps / 1e3, len(out) // steps))
+    agg = {}
+    for g, a, b in out:
+        k = (a.replace('void ', '')[:60], b.replace('void ', '')[:60])
+        agg.setdefault(k, []).append(g)
+    for (a, b), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
+        print('  %8.1f us/step  (%4.1f x %6.1f us)  after %s  before %s' %
+              (sum(v) / steps / 1e3, len(v) / steps, sum(v) / len(v) / 1e3, a, b))
 
 
 if __name__ == '__main__':
