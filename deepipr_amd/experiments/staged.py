@@ -136,6 +136,7 @@ class StagedStep:
         self.static_data, self.static_target = data.clone(), target.clone()
         self.recaptures = 0
         self._graphs = None
+        self._one = None
         # ---- analysis + warm-up (eager, no collective before the last stage has run): which stages hold split-channel
         # launches, MIOpen algorithm selection, allocator pools, lazily created state -- all outside any capture
         if self.graph:
@@ -183,7 +184,7 @@ class StagedStep:
         if not st.cut:
             return None
         ups = rec.up.get(st.cut, [])
-        nxt, nxt_g = [objective], [None]
+        nxt, nxt_g = [objective], [self._one]
         for u, g in zip(ups, grads[:len(leaves)]):
             if g is not None:
                 nxt.append(u)
@@ -195,7 +196,11 @@ class StagedStep:
         rec = cuts.CutRecorder(self.names)
         with rec:
             objective, outputs = self.forward_loss(self.model, data, target)
-        state = self._stage_backward(0, (objective, rec, [objective], [None]))
+        # an explicit d objective / d objective = 1 (a constant kept by the stepper): torch would otherwise launch a
+        # ones_like fill kernel for the scalar root in every stage
+        if self._one is None or self._one.device != objective.device or self._one.dtype != objective.dtype:
+            self._one = torch.ones_like(objective)
+        state = self._stage_backward(0, (objective, rec, [objective], [self._one]))
         return outputs, state
 
     # ------------------------------------------------------------------ exchange schedule (identical on every rank)

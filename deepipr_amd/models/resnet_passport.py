@@ -124,18 +124,13 @@ class ResNetPassport(nn.Module):
     def backward_stages(self):
         """Stages of the staged data-parallel backward (experiments/staged.py), last layers first:
         [(cut name = the activation that bounds the stage from below, modules whose gradients are complete once the
-        stage has run)].  75 % of a ResNet18's parameter bytes sit in layer4 (42 % in its last block), 19 % in
-        layer3, 6 % in everything before: the gradient buckets of flat_sgd.py follow these stages."""
-        l4 = list(self.layer4)
-        stages = []
-        if len(l4) > 1:
-            stages.append(('layer4.1', l4[1:] + [self.linear]))
-            stages.append(('layer4.0', [l4[0]]))
-        else:
-            stages.append(('layer4.0', l4 + [self.linear]))
-        stages.append(('layer3.0', [self.layer3]))
-        stages.append((None, [self.convbnrelu_1, self.layer1, self.layer2]))
-        return stages
+        stage has run)].  75 % of a ResNet18's parameter bytes sit in layer4, 19 % in layer3, 6 % in everything before:
+        the gradient buckets of flat_sgd.py follow these stages.  Three stages, not more: every extra hipGraph per step
+        costs 30-140 us on this runtime (profiles/r03_staged_probe_v1.json), and layer4's bucket -- launched behind the
+        first stage -- has all of layer3's backward to travel under; layer3 is a stage of its own because the layers
+        before it run split-channel kernels, which are kept clear of collectives (staged.py)."""
+        return [('layer4.0', [self.layer4, self.linear]), ('layer3.0', [self.layer3]),
+                (None, [self.convbnrelu_1, self.layer1, self.layer2])]
 
     def passport_layers(self):
         return [m for m in self.modules() if isinstance(m, PASSPORT_TYPES)]
@@ -146,7 +141,7 @@ class ResNetPassport(nn.Module):
             out, skip = self._stem(x, force_passport, ind)
             for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
                 for bi, block in enumerate(layer):
-                    if li >= 2 and bi <= 1:                      # the cut points backward_stages() names
+                    if li >= 2 and bi == 0:                      # the cut points backward_stages() names
                         out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
                     out, skip = block.forward_pair(out, skip, force_passport, ind)
         out = F.adaptive_avg_pool2d(out, (1, 1))

@@ -553,7 +553,7 @@ def test_staged_backward_equals_one_backward_pass(private, cpu_kernels):
     oa = FlatSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)     # the same update arithmetic on both sides
     ob = FlatSGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
     staged = StagedStep(step, wb, ob, x, y, graph=False, warmup=0)
-    assert [s.cut for s in staged.stages] == ['layer4.1', 'layer4.0', 'layer3.0', None] and ob._mode == 'staged'
+    assert [s.cut for s in staged.stages] == ['layer4.0', 'layer3.0', None] and ob._mode == 'staged'
     assert sum(len(s.params) for s in staged.stages) == len(list(b.parameters()))
     for it in range(2):
         out_a = step(wa, oa, x, y)
