@@ -43,8 +43,10 @@ def make_parser(private):
     p.add_argument('--ddp', action='store_true', default=False,
                    help='DistributedDataParallel + torch SGD instead of the default FlatSGD data parallelism')
     p.add_argument('--graph', action='store_true', default=False,
-                   help='replay the train step from a captured hipGraph (the default with several GPUs: forward + '
-                        'backward are replayed, one all-reduce of the flat gradient buffer and the fused SGD run after each replay)')
+                   help='(the default on the GPU; kept for compatibility) replay the train step from captured hipGraphs: '
+                        'one GPU: the whole step; several: forward + backward in stages, the gradient buckets all-reduced '
+                        'between the replays, one fused SGD kernel')
     p.add_argument('--eager', action='store_true', default=False,
-                   help='eager dispatch also with several GPUs (gradient exchange overlapped with backward)')
+                   help='eager dispatch instead of hipGraph replay (several GPUs: gradient exchange launched from '
+                        'gradient hooks, overlapped with backward)')
     return p

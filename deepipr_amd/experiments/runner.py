@@ -176,11 +176,11 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
         opt = FlatSGD(model.parameters(), lr=args['lr'], momentum=0.9, weight_decay=0.0001)
         wrap = lambda m: m
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, steps, lr_config['gamma']) if len(steps) else None
-    # hipGraph replay: opt-in on one GPU (--graph), the default with several (--eager switches it off): at 32-64
-    # images per GPU the eager step is host-bound (~500 dispatches), a replayed one is not.  DDP's own hooks cannot
-    # be captured.
-    graph = (bool(args.get('graph')) or (world > 1 and device.type == 'cuda' and not args.get('eager'))) \
-        and not args.get('ddp')
+    # hipGraph replay is the default on the GPU (--eager switches it off): at the reference's batch sizes the eager step is
+    # host-bound (~250-500 dispatches through Python autograd: config R +7 %, the 32-image shard of config P +46 %,
+    # DESIGN.md 5); a replayed one is not.  One GPU: the whole step is one graph; several: the staged step
+    # (experiments/staged.py).  Ragged last batches run the eager step.  DDP's own hooks cannot be captured.
+    graph = device.type == 'cuda' and not args.get('eager') and not args.get('ddp')
     if private:
         net = wrap(DualBranch(model))
         trainer = TrainerPrivate(net, opt, sched, device, graph=graph)

@@ -79,3 +79,24 @@ def test_experiment_ids_best_checkpoint_and_eval(cpu_kernels, tmp_path, capsys):
     assert 'No such Experiment' not in capsys.readouterr().out
     train_v1.main(common + ['--eval', '--exp-id', '9'])
     assert 'No such Experiment' in capsys.readouterr().out
+
+
+def test_use_trigger_as_passport_switches_the_passport_images(cpu_kernels, tmp_path):
+    """--use-trigger-as-passport (experiments/classification.py:37-40): the passport images are drawn from the trigger
+    set instead of the validation set, so the keys -- activations of those images in the plain net -- differ, with
+    everything else (seeds, weights, python `random` draws) equal."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import train_v1
+    common = ['--arch', 'alexnet', '--train-passport', '--key-type', 'image', '--epochs', '1', '--batch-size', '4',
+              '--synthetic-samples', '8', '--device', 'cpu', '--logdir', str(tmp_path)]
+    import random
+
+    def run(extra):
+        random.seed(5)                            # passport_generator.get_key draws the image indices from `random`
+        return train_v1.main(common + extra)
+    a, b, c = run([]), run(['--use-trigger-as-passport']), run([])
+    ka, kb, kc = (torch.load(os.path.join(o['logdir'], 'models', 'last.pth'))['features.4.key'] for o in (a, b, c))
+    assert tuple(ka.shape) == (1, 192, 8, 8)
+    assert torch.equal(ka, kc)                    # same flags, same keys
+    assert not torch.equal(ka, kb)                # other passport images, other keys

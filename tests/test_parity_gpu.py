@@ -871,7 +871,8 @@ def test_trainer_graph_mode_equals_eager_epoch():
 
 
 def test_entry_points_run_on_the_gpu(tmp_path, monkeypatch):
-    """train_v1.py (shuffle keys, hipGraph replay) and train_v23.py --train-backdoor end to end on synthetic data."""
+    """train_v1.py (shuffle keys drawn from the trigger set; hipGraph replay is the default on the GPU) and
+    train_v23.py --train-backdoor end to end on synthetic data."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -881,7 +882,7 @@ def test_entry_points_run_on_the_gpu(tmp_path, monkeypatch):
     import train_v23
     out = train_v1.main(['--arch', 'resnet', '--train-passport', '--key-type', 'shuffle', '--epochs', '2',
                          '--passport-config', 'passport_configs/resnet18_passport.json', '--batch-size', '64',
-                         '--synthetic-samples', '256', '--graph', '--logdir', str(tmp_path)])
+                         '--synthetic-samples', '256', '--use-trigger-as-passport', '--logdir', str(tmp_path)])
     h = out['history']
     assert len(h) == 2 and all(np.isfinite(r['train_loss']) for r in h) and h[0]['train_sign_loss'] > 0
     assert h[1]['train_sign_loss'] < h[0]['train_sign_loss']          # the hinge is being driven down
