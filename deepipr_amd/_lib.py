@@ -25,6 +25,10 @@ _int, _flt, _sz = _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     'deepipr_abi_version': (_int, []),
     'deepipr_last_error': (_c.c_char_p, []),
+    'deepipr_event_create': (_int, [_c.POINTER(_c.c_void_p)]),
+    'deepipr_event_destroy': (_int, [_vp]),
+    'deepipr_event_record': (_int, [_vp, _vp]),
+    'deepipr_stream_wait_event': (_int, [_vp, _vp]),
     'deepipr_profile_enable': (_int, [_int]),
     'deepipr_profile_read': (_int, [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
     'deepipr_pooled_patch_mean': (_int, [_f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f64p, _vp]),
@@ -148,6 +152,31 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd']
+
+
+class ExternalEvent:
+    """An event a captured step records from INSIDE its hipGraph (deepipr_event_record on the capturing stream adds an
+    external event-record node) and another stream waits for after the launch: how experiments/staged.py starts a
+    gradient bucket's all-reduce while the replayed backward is still running.  Has torch.cuda.Event's `wait`."""
+
+    def __init__(self):
+        h = _c.c_void_p()
+        check(lib().deepipr_event_create(_c.byref(h)), 'event_create')
+        self.handle = h.value
+
+    def record(self, stream):
+        """stream: a torch.cuda.Stream (capturing or not)."""
+        check(lib().deepipr_event_record(self.handle, stream.cuda_stream), 'event_record')
+
+    def wait(self, stream):
+        check(lib().deepipr_stream_wait_event(stream.cuda_stream, self.handle), 'stream_wait_event')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().deepipr_event_destroy(self.handle)
+        except Exception:
+            pass
 
 
 def has_test_hooks():

@@ -2508,6 +2508,58 @@ int deepipr_abi_version(void) { return DEEPIPR_ABI_VERSION; }
 
 const char *deepipr_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------------------------------------
+// External events: the hook a captured step offers to work OUTSIDE the graph (include/deepipr_hip.h)
+int deepipr_event_create(void **event) {
+    if (!event) return fail(DEEPIPR_EINVAL, "event_create: null argument");
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return fail(DEEPIPR_ELAUNCH, "event_create: %s", hipGetErrorString(rc));
+    *event = e;
+    return DEEPIPR_OK;
+}
+
+int deepipr_event_destroy(void *event) {
+    if (!event) return DEEPIPR_OK;
+    const hipError_t rc = hipEventDestroy(static_cast<hipEvent_t>(event));
+    return rc == hipSuccess ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "event_destroy: %s", hipGetErrorString(rc));
+}
+
+int deepipr_event_record(void *event, void *stream) {
+    if (!event) return fail(DEEPIPR_EINVAL, "event_record: null event");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t ev = static_cast<hipEvent_t>(event);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t *deps = nullptr;
+    size_t ndeps = 0;
+    if (hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &ndeps) != hipSuccess) {
+        (void)hipGetLastError();
+        cs = hipStreamCaptureStatusNone;
+    }
+    hipError_t rc;
+    if (cs == hipStreamCaptureStatusActive) {
+        // On a capturing stream: an event-record NODE behind everything captured so far, and the capture continues
+        // behind the node.  Every launch of the graph records the event when its execution reaches the node; a
+        // hipStreamWaitEvent issued after the launch call waits for exactly that record.  (The one-call form,
+        // hipEventRecordWithFlags(hipEventRecordExternal), returns hipErrorInvalidValue under torch's capture on
+        // ROCm 7.0; the explicit node does the same thing.)
+        hipGraphNode_t node = nullptr;
+        rc = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev);
+        if (rc == hipSuccess) rc = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+    } else {
+        rc = hipEventRecord(ev, st);
+    }
+    return rc == hipSuccess ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "event_record: %s", hipGetErrorString(rc));
+}
+
+int deepipr_stream_wait_event(void *stream, void *event) {
+    if (!event) return fail(DEEPIPR_EINVAL, "stream_wait_event: null event");
+    const hipError_t rc = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0);
+    return rc == hipSuccess ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "stream_wait_event: %s", hipGetErrorString(rc));
+}
+
 int deepipr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (on == 1) {                                   // 1 = start afresh, 2 = resume, 0 = pause

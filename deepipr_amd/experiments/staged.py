@@ -9,26 +9,35 @@ not, but no hook can fire inside it, so round 2 exchanged everything after the r
 both: the backward pass is cut into a few STAGES at activations the model names (deepipr_amd/cuts.py,
 model.backward_stages()) and
 
-    stage 0   zero_grad, forward, losses, backward down to the first cut        | one hipGraph (or eager)
-    stage k   backward from cut k-1 down to cut k (torch.autograd.grad on the   | one hipGraph each
-              detached cut leaves; the objective stays a root so that sign
-              losses of layers in later stages keep their gradient)
-    between   bucket k (= the parameters whose gradients stage k finished) is packed and all-reduced on a SIDE
-              stream that waits for an event recorded behind stage k, while the main stream replays stage k + 1
+    stage 0   zero_grad, forward, losses, backward down to the first cut
+    stage k   backward from cut k-1 down to cut k (torch.autograd.grad on the detached cut leaves; the objective stays
+              a root so that sign losses of layers in later stages keep their gradient)
+    between   bucket k (= the parameters whose gradients stage k finished) is packed and all-reduced on a SIDE stream
+              while the main stream goes on with stage k + 1
     end       remaining buckets as one message, wait, ONE fused SGD kernel (FlatSGD.step)
 
-No collective is ever captured; the order of collectives is fixed by the stage plan, which depends only on the model
-and the batch shape, i.e. it is identical on every rank.
+Replayed form.  The stages are captured back to back into ONE hipGraph; behind every stage the capture records an
+EXTERNAL event (deepipr_event_record: an event-record node in the captured graph).  A
+step is then: launch the graph; for every bucket make the side stream wait for that bucket's event and enqueue pack +
+all-reduce there; FlatSGD.step.  The graph is not split (every extra graph launch per step measured 30-140 us on this
+runtime, 250 us for three graphs: profiles/r03_staged_probe_v1.json, r03_ddp_rehearsal.jsonl) and no collective is
+ever captured.  The order of collectives is fixed by the stage plan, which depends only on the model and the batch
+shape, i.e. it is identical on every rank.
 
 Split-channel kernels.  The single-pass norm kernels of layers with fewer channels than CUs exchange partial sums
-inside the launch and need all their workgroups co-resident (csrc: res_exchange).  A concurrent collective can delay
-that, so by default ("exclusive") a stage that contains such launches never overlaps a collective: outstanding
-all-reduces are waited for in front of it and the bucket finished just before it is exchanged after it.  For
-ResNet18 that is the last stage only (stem, layer1, layer2: 6 % of the gradient bytes): 75 % of the bytes (layer4) travel
-under layer3's backward, 25 % (11 MB) after the last stage.  DEEPIPR_OVERLAP_SYNC=1 ("shared") overlaps those stages
-too -- the in-launch wait is bounded at seconds, a collective lasts well under a millisecond -- and leaves only the
-last 2.7 MB exposed; it is not the default because it cannot be measured on a single GPU.  The user's switch
-DEEPIPR_ALLOW_SYNC=0 removes the split-channel kernels altogether (then every stage overlaps).
+inside the launch and need all their workgroups co-resident (csrc: res_exchange).  A collective that still runs when
+such a kernel starts holds some CUs, so part of its workgroups start only when the collective has finished: the
+overlap degenerates to serialisation for that stretch, nothing worse -- the in-launch wait is bounded at seconds, a
+collective of this size lasts well under a millisecond, and a collective kernel never waits for a kernel of this
+library, so there is no cycle.  Two policies:
+    "shared"     (default) collectives may overlap every stage; only the last bucket (ResNet18: 2.7 MB) is exposed;
+    "exclusive"  (DEEPIPR_OVERLAP_SYNC=0) a stage that contains split-channel launches never overlaps a collective:
+                 outstanding all-reduces are waited for in front of it (the graph is split there, the one place where
+                 the host has to hold the stream back) and the bucket finished just before it travels after it.  For
+                 ResNet18 that is the last stage (stem, layer1, layer2): layer4's 75 % of the bytes travel under
+                 layer3's backward, 25 % (11 MB) after the last stage.
+The user's switch DEEPIPR_ALLOW_SYNC=0 removes the split-channel kernels altogether.  A time-out, should one ever
+happen, is loud (NaN statistics + the flag Trainer / bench.py check).
 """
 import os
 
@@ -119,7 +128,7 @@ class StagedStep:
         self.model, self.optimizer = model, optimizer
         self.graph = data.is_cuda if graph is None else bool(graph)
         if overlap_sync is None:
-            overlap_sync = os.environ.get('DEEPIPR_OVERLAP_SYNC') == '1'
+            overlap_sync = os.environ.get('DEEPIPR_OVERLAP_SYNC', '1') != '0'
         self.overlap_sync = bool(overlap_sync)
         self.stages = plan_stages(model, optimizer)
         self.flat = hasattr(optimizer, 'configure_stages')
@@ -242,25 +251,43 @@ class StagedStep:
         return outputs
 
     # ------------------------------------------------------------------ captured form
+    def _groups(self):
+        """Stages -> hipGraphs: ONE graph, split only in front of a stage the host has to hold back for (exclusive
+        policy: a stage with split-channel launches waits for the outstanding collectives)."""
+        groups = [[0]]
+        for k in range(1, len(self.stages)):
+            if self.flat and self._exclusive(k):
+                groups.append([k])
+            else:
+                groups[-1].append(k)
+        return groups
+
     def _capture(self):
+        from deepipr_amd import _lib
         opt = self.optimizer
         self._device_hyper = hasattr(opt, 'sync_hyper')
         if self._device_hyper:
             opt.sync_hyper()
         mode = 'thread_local' if torch.distributed.is_available() and torch.distributed.is_initialized() else 'global'
         pool = torch.cuda.graph_pool_handle()
-        graphs, state = [], None
+        self._plan, self._events, state = [], {}, None
         opt.zero_grad(set_to_none=True)
         with self._scope():
-            for k in range(len(self.stages)):
+            for group in self._groups():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, stream=self.stream, capture_error_mode=mode):
-                    if k == 0:
-                        self.outputs, state = self._stage0(self.static_data, self.static_target)
-                    else:
-                        state = self._stage_backward(k, state)
-                graphs.append(g)
-        self._graphs = graphs
+                    for k in group:
+                        if k == 0:
+                            self.outputs, state = self._stage0(self.static_data, self.static_target)
+                        else:
+                            state = self._stage_backward(k, state)
+                        if self.flat and k != group[-1]:
+                            # stage k's gradients are complete here: an external event-record node the side stream
+                            # will wait for after the launch
+                            self._events[k] = _lib.ExternalEvent()
+                            self._events[k].record(self.stream)
+                self._plan.append((g, group))
+        self._graphs = [g for g, _ in self._plan]
         # the gradient tensors the replays write (graph-pool memory): `.grad` must point at them whenever the optimiser
         # runs, also after an eager step in between (a ragged last batch) re-bound it
         self._captured_grads = [(p, p.grad) for g in opt.param_groups for p in g['params']]
@@ -275,11 +302,15 @@ class StagedStep:
         self.static_target.copy_(target, non_blocking=True)
         for p, g in self._captured_grads:
             p.grad = g
-        self._pending_lo = 0
-        for k, g in enumerate(self._graphs):
-            self._before_stage(k)
+        lo = 0
+        for i, (g, group) in enumerate(self._plan):
+            if i:
+                opt.wait_exchange()                     # exclusive policy: nothing in flight while this graph runs
             g.replay()
-            self._after_stage(k)
+            for k in group:
+                if k in self._events:                   # bucket(s) up to stage k: pack + all-reduce on the side stream
+                    opt.exchange_stages(lo, k + 1, after=self._events[k], overlap=True)
+                    lo = k + 1
         opt.step()
         return self.outputs
 
@@ -288,4 +319,5 @@ class StagedStep:
         return {'stages': [{'cut': s.cut, 'params': len(s.params), 'split_channel_kernels': s.has_sync,
                             'bucket_MB': round(sizes[i] / 1e6, 2) if i < len(sizes) else None}
                            for i, s in enumerate(self.stages)],
-                'policy': 'shared' if self.overlap_sync else 'exclusive', 'graph': self.graph}
+                'policy': 'shared' if self.overlap_sync else 'exclusive', 'graph': self.graph,
+                'graphs_per_step': len(self._graphs) if self._graphs else 0}

@@ -237,7 +237,7 @@ class FlatSGD(torch.optim.Optimizer):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.flat_grad.device)
             if after is not None:
-                self._side.wait_event(after)
+                after.wait(self._side)              # a torch.cuda.Event, or the external event of a captured stage
             else:
                 self._side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
             with torch.cuda.stream(self._side):

@@ -125,10 +125,9 @@ class ResNetPassport(nn.Module):
         """Stages of the staged data-parallel backward (experiments/staged.py), last layers first:
         [(cut name = the activation that bounds the stage from below, modules whose gradients are complete once the
         stage has run)].  75 % of a ResNet18's parameter bytes sit in layer4, 19 % in layer3, 6 % in everything before:
-        the gradient buckets of flat_sgd.py follow these stages.  Three stages, not more: every extra hipGraph per step
-        costs 30-140 us on this runtime (profiles/r03_staged_probe_v1.json), and layer4's bucket -- launched behind the
-        first stage -- has all of layer3's backward to travel under; layer3 is a stage of its own because the layers
-        before it run split-channel kernels, which are kept clear of collectives (staged.py)."""
+        the gradient buckets of flat_sgd.py follow these stages -- few, large messages (xGMI is point-to-point and
+        per-link bound); layer3 is a stage of its own because the layers before it run split-channel kernels, which the
+        "exclusive" exchange policy keeps clear of collectives (staged.py)."""
         return [('layer4.0', [self.layer4, self.linear]), ('layer3.0', [self.layer3]),
                 (None, [self.convbnrelu_1, self.layer1, self.layer2])]
 

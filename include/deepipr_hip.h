@@ -36,6 +36,20 @@ extern "C" {
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
 
+/* ------------------------------------------------------------------ external events of a captured step
+ * A train step captured into a hipGraph cannot call back into the host, yet a data-parallel step wants to start the
+ * all-reduce of a gradient bucket the moment backward has finished it (the reference gathers gradients only after
+ * backward, experiments/trainer.py:92-93).  deepipr_event_record on a CAPTURING stream adds an event-record node
+ * behind everything captured so far (hipGraphAddEventRecordNode on the capture's graph, the capture continues behind
+ * it): each launch of the graph records the event when execution
+ * reaches that point; after the launch call the host makes another stream wait for it (deepipr_stream_wait_event) and
+ * enqueues the collective there -- no collective is captured, the graph is not split.  On a stream that is not
+ * capturing, deepipr_event_record is a plain hipEventRecord.  Events are created without timing. */
+int deepipr_event_create(void **event);
+int deepipr_event_destroy(void *event);
+int deepipr_event_record(void *event, void *stream);
+int deepipr_stream_wait_event(void *stream, void *event);
+
 /* Opt-in in-situ timing (the one piece of process-global state, off by default): while enabled every
  * kernel below is dispatched through hipExtLaunchKernelGGL with a start and a stop hipEvent attached to
  * its own dispatch packet on the launch stream, so the elapsed time is the kernel's execution time (what

@@ -19,3 +19,23 @@ def compare_case(got, gold, rtol, atol, skip_prefixes=()):
             assert np.array_equal(got[k], gold[k]), k
         else:
             close(got[k], gold[k], k, rtol, atol)
+
+
+def states_close(a, b, rtol=1e-3, atol=1e-5, what='state'):
+    """Two state_dicts (same keys) of torch tensors: every floating tensor allclose; a failure reports HOW the two
+    differ (how many tensors, the largest relative deviations, whether they are bit-identical elsewhere) instead of
+    the first key only -- a rounding-level divergence and a read of freed memory look very different here."""
+    import torch
+    bad, exact = [], 0
+    for k in a:
+        if not a[k].dtype.is_floating_point:
+            continue
+        if torch.equal(a[k], b[k]):
+            exact += 1
+            continue
+        if not torch.allclose(a[k], b[k], rtol=rtol, atol=atol):
+            d = (a[k].double() - b[k].double()).abs()
+            bad.append((float(d.max() / (a[k].double().abs().max() + 1e-30)), k, int((d > atol + rtol * b[k].double().abs()).sum()),
+                        a[k].numel(), bool(torch.isfinite(b[k]).all())))
+    assert not bad, ('%s: %d tensors differ beyond rtol %g (%d bit-identical); worst (max|d|/max|a|, name, elements off, '
+                     'numel, finite): %s' % (what, len(bad), rtol, exact, sorted(bad, reverse=True)[:6]))

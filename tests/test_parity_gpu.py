@@ -11,7 +11,7 @@ import torch
 from oracle import np_passport as npp
 from oracle import patterns, runner, torch_ref
 from oracle.cases import ALPHA, CASES, SGD, resnet18_config
-from tests.compare import close, compare_case
+from tests.compare import close, states_close, compare_case
 from tests.impls import ProductImpl, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -835,9 +835,7 @@ def test_graphed_step_equals_eager_step():
     (sd_e, out_e), (sd_g, out_g) = results
     for a, b in zip(out_e, out_g):
         assert a == pytest.approx(b, rel=1e-4, abs=1e-5)
-    for k in sd_e:
-        if sd_e[k].dtype.is_floating_point:
-            assert torch.allclose(sd_e[k], sd_g[k], rtol=1e-3, atol=1e-5), k
+    states_close(sd_e, sd_g, what='eager vs graphed')
 
 
 @pytest.mark.miopen_pinned
@@ -863,10 +861,9 @@ def test_trainer_graph_mode_equals_eager_epoch():
     for (rg, sg) in outs[1:]:
         for k in ('loss', 'sign_loss', 'sign_acc', 'acc'):
             assert re[k] == pytest.approx(rg[k], rel=1e-4, abs=1e-5), k
+        states_close(se, sg, what='eager epoch vs graph-mode epoch')
         for k in se:
-            if se[k].dtype.is_floating_point:
-                assert torch.allclose(se[k], sg[k], rtol=1e-3, atol=1e-5), k
-            else:
+            if not se[k].dtype.is_floating_point:
                 assert torch.equal(se[k], sg[k]), k
 
 
@@ -946,9 +943,7 @@ def test_flat_sgd_equals_torch_sgd_on_gpu(K):
             finals.append({k: v.clone() for k, v in prod.state_dict().items()})
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
-    for k in finals[0]:
-        if finals[0][k].dtype.is_floating_point:
-            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+    states_close(finals[0], finals[1], what='eager vs replayed')
 
 
 def test_convblock_fused_norm_equals_library_ops():
@@ -1056,22 +1051,27 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
         finals = []
-        for graphed in (False, True, 'staged'):
+        for graphed in (False, True, 'staged', 'staged-exclusive'):
             prod, _ref, x, y = _fullsize_pair(False, 32, 10)
             x, y = x.to(DEV), y.to(DEV)
             opt = FlatSGD(prod.parameters(), **SGD)
             assert opt.comm and len(opt._buckets) >= 3
-            if graphed == 'staged':
-                # the default with several GPUs: one graph per backward stage, bucket all-reduces launched between the
-                # replays on a side stream (experiments/staged.py)
+            if graphed in ('staged', 'staged-exclusive'):
+                # the default with several GPUs (experiments/staged.py): the backward stages in ONE graph with an external
+                # event behind each, the bucket all-reduces enqueued on a side stream behind those events; "exclusive":
+                # the graph is split in front of the stage with split-channel kernels, which waits for the collectives
                 from deepipr_amd.experiments.staged import StagedStep
-                g = StagedStep(train_step_v1, prod, opt, x, y, graph=True, warmup=0)
+                g = StagedStep(train_step_v1, prod, opt, x, y, graph=True, warmup=0,
+                               overlap_sync=graphed == 'staged')
                 plan = g.describe()
+                assert plan['policy'] == ('shared' if graphed == 'staged' else 'exclusive')
+                assert plan['graphs_per_step'] == (1 if graphed == 'staged' else 2), plan
+                assert sorted(g._events) == ([0, 1] if graphed == 'staged' else [0])
                 assert [s['cut'] for s in plan['stages']] == ['layer4.0', 'layer3.0', None], plan
                 # (stage 0 holds the forward pass, whose stem / layer1 / layer2 launches are split-channel -- harmless:
                 # nothing is in flight before it; of the backward stages only the last one has them)
                 assert [s['split_channel_kernels'] for s in plan['stages']][1:] == [False, True], plan
-                assert opt._mode == 'staged' and len(g._graphs) == 3
+                assert opt._mode == 'staged'
                 for i in range(3):
                     g(x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
             elif graphed:
@@ -1083,10 +1083,8 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
                     train_step_v1(prod, opt, x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
             torch.cuda.synchronize()
             finals.append({k: v.clone() for k, v in prod.state_dict().items()})
-        for k in finals[0]:
-            if finals[0][k].dtype.is_floating_point:
-                assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
-                assert torch.allclose(finals[0][k], finals[2][k], rtol=1e-3, atol=1e-5), k
+        for i, name in ((1, 'one graph + exchange after it'), (2, 'staged, shared'), (3, 'staged, exclusive')):
+            states_close(finals[0], finals[i], what='eager vs ' + name)
         passport_ops.kernels.check_exchange()
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det

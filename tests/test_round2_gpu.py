@@ -17,7 +17,7 @@ import torch
 
 from oracle import patterns, torch_ref
 from oracle.cases import ALPHA, SGD, alexnet_config
-from tests.compare import close
+from tests.compare import close, states_close
 from tests.impls import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -468,9 +468,7 @@ def test_graph_replay_follows_the_lr_schedule(K, flat):
             assert g.recaptures == (0 if flat else 2)
         finals.append({k: v.clone() for k, v in prod.state_dict().items()})
         assert opt.param_groups[0]['lr'] == pytest.approx(0.0005)
-    for k in finals[0]:
-        if finals[0][k].dtype.is_floating_point:
-            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+    states_close(finals[0], finals[1], what='eager vs replayed')
     # and the schedule really acted: a frozen lr of 0.05 would have moved the weights ~3.4x further in epochs 2-3
     assert K.sync_timeouts() == 0
 
@@ -501,9 +499,7 @@ def test_captured_flat_sgd_reads_gradients_in_place(K):
                 assert opt.in_place_captures == 0
             torch.cuda.synchronize()
         finals.append({k: v.clone() for k, v in prod.state_dict().items()})
-    for k in finals[0]:
-        if finals[0][k].dtype.is_floating_point:
-            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+    states_close(finals[0], finals[1], what='eager vs replayed')
 
 
 @pytest.mark.parametrize('n,c', [(128, 10), (66, 100), (32, 100), (8, 1000), (256, 1000), (1, 2), (7, 1)])
@@ -555,6 +551,4 @@ def test_replay_with_eager_optimizer_survives_an_eager_step_in_between(K):
                     train_step_v1(prod, opt, xb, yb)
             torch.cuda.synchronize()
         finals.append({k: v.clone() for k, v in prod.state_dict().items()})
-    for k in finals[0]:
-        if finals[0][k].dtype.is_floating_point:
-            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-3, atol=1e-5), k
+    states_close(finals[0], finals[1], what='eager vs replayed')

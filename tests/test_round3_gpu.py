@@ -321,3 +321,41 @@ def test_single_pass_in_channel_range_passes_on_large_maps(K, shape, mode):
     # the two forms of the library on the same inputs: statistics from f64 sums in both -> outputs within an ulp or two
     assert np.abs(host(o_3l[0]) - y_g).max() <= 4e-6 * (1 + np.abs(y_g).max())
     assert np.abs(host(b_3l[0]) - dx_g).max() <= 2e-5 * scale
+
+
+# ----------------------------------------------------------------------------- external events of a captured step
+def test_external_event_of_a_captured_graph_orders_a_side_stream(K):
+    """deepipr_event_record on a capturing stream = an external event-record node: after every launch of the graph, a
+    stream made to wait for the event (deepipr_stream_wait_event, issued after the launch call) must see everything the
+    graph did BEFORE the node -- this is what lets experiments/staged.py start a gradient bucket's all-reduce from
+    outside the graph while the replayed backward is still running.  A wait that bound to an older record, or returned
+    early, would let the side stream read the previous replay's values."""
+    from deepipr_amd import _lib
+    dev_ = torch.device(DEV)
+    big = torch.zeros(1 << 26, device=dev_)                    # 256 MB: the increment below takes ~100 us
+    tail = torch.zeros(1 << 26, device=dev_)
+    cap, side = torch.cuda.Stream(device=dev_), torch.cuda.Stream(device=dev_)
+    ev = _lib.ExternalEvent()
+    cap.wait_stream(torch.cuda.current_stream(dev_))
+    with torch.cuda.stream(cap):
+        big.add_(0.0)                                          # warm the kernels outside the capture
+        tail.add_(0.0)
+    torch.cuda.current_stream(dev_).wait_stream(cap)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        big.add_(1.0)
+        ev.record(cap)                                         # <- external event-record node
+        for _ in range(4):
+            tail.add_(1.0)                                     # work behind the node: the graph is still running
+    torch.cuda.synchronize()
+    for i in range(1, 31):
+        g.replay()
+        ev.wait(side)
+        with torch.cuda.stream(side):
+            snap = big[:: 1 << 12].clone()                     # strided sample across the whole buffer
+            done = tail[:: 1 << 16].clone()
+        side.synchronize()
+        assert bool((snap == float(i)).all()), (i, snap.unique().tolist())
+        # (not asserted: `done` usually still holds a value below 4 * i -- the side stream ran ahead of the graph's tail)
+        assert float(done.max()) <= 4.0 * i
+    torch.cuda.synchronize()

@@ -81,12 +81,13 @@ def main():
             return st
         S.plan_stages = plan
         for noxchg in (False, True):
-            name = 'staged-%d%s' % (4 - merge, '-noxchg' if noxchg else '')
+            name = 'staged-%d%s' % (max(1, 3 - merge), '-noxchg' if noxchg else '')
             if a.only and a.only != name:
                 continue
             net, opt = fresh()
             st = S.StagedStep(fn, net, opt, x, y, graph=True)
             if noxchg:
+                st._events = {}                    # captured event nodes stay; nothing is launched behind them
                 st._after_stage = lambda k: None
                 st._before_stage = lambda k: None
             measure('staged-%d%s' % (len(st.stages), '-noxchg' if noxchg else ''), lambda: st(x, y))
