@@ -410,9 +410,12 @@ def main():
     if use_graph and tdist_on and hasattr(graphed, 'describe'):
         stage_plan = graphed.describe()
         opt.exposed_events = []
+        graphed.host_times = {}
         for i in range(20):
             step(i)
         torch.cuda.synchronize()
+        ht, graphed.host_times = graphed.host_times, None
+        stage_plan['host_us_per_step'] = {k: round(1e6 * v / 20, 1) for k, v in ht.items() if not k.startswith('calls_')}
         if opt.exposed_events:
             exposed_us = 1000.0 * sum(a.elapsed_time(b) for a, b in opt.exposed_events) / len(opt.exposed_events)
             exposed_us = D.max_over_ranks(exposed_us, device)

@@ -29,6 +29,7 @@ SIGNATURES = {
     'deepipr_event_destroy': (_int, [_vp]),
     'deepipr_event_record': (_int, [_vp, _vp]),
     'deepipr_stream_wait_event': (_int, [_vp, _vp]),
+    'deepipr_event_synchronize': (_int, [_vp]),
     'deepipr_profile_enable': (_int, [_int]),
     'deepipr_profile_read': (_int, [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
     'deepipr_pooled_patch_mean': (_int, [_f32p, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f64p, _vp]),
@@ -170,6 +171,10 @@ class ExternalEvent:
 
     def wait(self, stream):
         check(lib().deepipr_stream_wait_event(stream.cuda_stream, self.handle), 'stream_wait_event')
+
+    def synchronize(self):
+        """Block the host until the latest record of the event has completed."""
+        check(lib().deepipr_event_synchronize(self.handle), 'event_synchronize')
 
     def __del__(self):
         try:

@@ -2554,6 +2554,12 @@ int deepipr_event_record(void *event, void *stream) {
     return rc == hipSuccess ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "event_record: %s", hipGetErrorString(rc));
 }
 
+int deepipr_event_synchronize(void *event) {
+    if (!event) return fail(DEEPIPR_EINVAL, "event_synchronize: null event");
+    const hipError_t rc = hipEventSynchronize(static_cast<hipEvent_t>(event));
+    return rc == hipSuccess ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "event_synchronize: %s", hipGetErrorString(rc));
+}
+
 int deepipr_stream_wait_event(void *stream, void *event) {
     if (!event) return fail(DEEPIPR_EINVAL, "stream_wait_event: null event");
     const hipError_t rc = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0);

@@ -16,13 +16,25 @@ model.backward_stages()) and
               while the main stream goes on with stage k + 1
     end       remaining buckets as one message, wait, ONE fused SGD kernel (FlatSGD.step)
 
-Replayed form.  The stages are captured back to back into ONE hipGraph; behind every stage the capture records an
-EXTERNAL event (deepipr_event_record: an event-record node in the captured graph).  A
-step is then: launch the graph; for every bucket make the side stream wait for that bucket's event and enqueue pack +
-all-reduce there; FlatSGD.step.  The graph is not split (every extra graph launch per step measured 30-140 us on this
-runtime, 250 us for three graphs: profiles/r03_staged_probe_v1.json, r03_ddp_rehearsal.jsonl) and no collective is
-ever captured.  The order of collectives is fixed by the stage plan, which depends only on the model and the batch
-shape, i.e. it is identical on every rank.
+Replayed form.  The stages are captured back to back into ONE hipGraph; behind every stage whose bucket is to travel
+under the rest of backward the capture packs the bucket into the flat gradient buffer and records an EXTERNAL event
+(deepipr_event_record: an event-record node in the captured graph).  A step is then: launch the graph; for every such
+bucket wait ON THE HOST until the graph has passed the event, then enqueue the all-reduce on a side stream;
+FlatSGD.step (remaining buckets, one fused SGD kernel).  The graph is not split and no collective is ever captured.
+What this costs was measured on one MI355X with the exchange forced on in a world of one
+(profiles/r03_ddp_rehearsal*.jsonl, r03_probe2*.json, r03_staged_probe_*.json):
+  * the cuts, torch.autograd.grad per stage and the event-record nodes cost nothing at replay (5.468 ms against
+    5.469 ms per step);
+  * splitting the step into several hipGraphs instead cost 30-140 us per extra graph;
+  * a STREAM-side wait for the event, enqueued right after the launch, sits in a second hardware queue for half a step
+    and slows every dispatch of the replayed graph next to it: +160 us per step for ResNet18 V1 (batch 128), +560 us for
+    the V2 shard (batch 32, twice the dispatches) -- whether one bucket or three.  Holding the HOST until the event has
+    fired and enqueuing the collective then removes that: +0.5-1 % over the step without any exchange (5.50 / 4.99 ms
+    against 5.42-5.47 / 4.95-4.97 ms).  The host has nothing else to do meanwhile: what it still has to enqueue for this
+    step and the next takes ~0.3 ms, the graph runs for 2-3 ms more (DEEPIPR_STAGED_HOST_WAIT=0 restores the stream-side
+    wait).
+The order of collectives is fixed by the stage plan, which depends only on the model and the batch shape, i.e. it is
+identical on every rank.
 
 Split-channel kernels.  The single-pass norm kernels of layers with fewer channels than CUs exchange partial sums
 inside the launch and need all their workgroups co-resident (csrc: res_exchange).  A collective that still runs when
@@ -30,7 +42,7 @@ such a kernel starts holds some CUs, so part of its workgroups start only when t
 overlap degenerates to serialisation for that stretch, nothing worse -- the in-launch wait is bounded at seconds, a
 collective of this size lasts well under a millisecond, and a collective kernel never waits for a kernel of this
 library, so there is no cycle.  Two policies:
-    "shared"     (default) collectives may overlap every stage; only the last bucket (ResNet18: 2.7 MB) is exposed;
+    "shared"     (default) collectives may overlap every stage; only the last stage's bucket (ResNet18: 2.7 MB) is exposed;
     "exclusive"  (DEEPIPR_OVERLAP_SYNC=0) a stage that contains split-channel launches never overlaps a collective:
                  outstanding all-reduces are waited for in front of it (the graph is split there, the one place where
                  the host has to hold the stream back) and the bucket finished just before it travels after it.  For
@@ -40,6 +52,7 @@ The user's switch DEEPIPR_ALLOW_SYNC=0 removes the split-channel kernels altoget
 happen, is loud (NaN statistics + the flag Trainer / bench.py check).
 """
 import os
+import time
 
 import torch
 
@@ -145,7 +158,10 @@ class StagedStep:
         self.static_data, self.static_target = data.clone(), target.clone()
         self.recaptures = 0
         self._graphs = None
+        self._plan, self._events = [], {}
         self._one = None
+        self.host_times = None            # set to {} to accumulate HOST time per phase of __call__ (diagnosis)
+        self.host_waits = os.environ.get('DEEPIPR_STAGED_HOST_WAIT', '1') != '0'
         # ---- analysis + warm-up (eager, no collective before the last stage has run): which stages hold split-channel
         # launches, MIOpen algorithm selection, allocator pools, lazily created state -- all outside any capture
         if self.graph:
@@ -251,12 +267,19 @@ class StagedStep:
         return outputs
 
     # ------------------------------------------------------------------ captured form
+    def _overlapped(self):
+        """Stages whose bucket is handed to the side stream right behind them (the rest travels at the end of the step):
+        every stage but the last whose successor may overlap a collective."""
+        n = len(self.stages)
+        return {j for j in range(n - 1) if self.flat and not self._exclusive(j + 1)}
+
     def _groups(self):
-        """Stages -> hipGraphs: ONE graph, split only in front of a stage the host has to hold back for (exclusive
-        policy: a stage with split-channel launches waits for the outstanding collectives)."""
+        """Stages -> hipGraphs: ONE graph, split only in front of a stage the host has to hold the stream back for
+        (exclusive policy: a stage with split-channel launches waits for the collectives launched before it)."""
+        launched = self._overlapped()
         groups = [[0]]
         for k in range(1, len(self.stages)):
-            if self.flat and self._exclusive(k):
+            if self.flat and self._exclusive(k) and any(j < k for j in launched):
                 groups.append([k])
             else:
                 groups[-1].append(k)
@@ -270,10 +293,12 @@ class StagedStep:
             opt.sync_hyper()
         mode = 'thread_local' if torch.distributed.is_available() and torch.distributed.is_initialized() else 'global'
         pool = torch.cuda.graph_pool_handle()
-        self._plan, self._events, state = [], {}, None
+        self._plan, self._events, self._ranges, state = [], {}, {}, None
         opt.zero_grad(set_to_none=True)
+        lo = 0
         with self._scope():
-            for group in self._groups():
+            groups, launched = self._groups(), self._overlapped()
+            for group in groups:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, stream=self.stream, capture_error_mode=mode):
                     for k in group:
@@ -281,11 +306,19 @@ class StagedStep:
                             self.outputs, state = self._stage0(self.static_data, self.static_target)
                         else:
                             state = self._stage_backward(k, state)
-                        if self.flat and k != group[-1]:
-                            # stage k's gradients are complete here: an external event-record node the side stream
-                            # will wait for after the launch
-                            self._events[k] = _lib.ExternalEvent()
-                            self._events[k].record(self.stream)
+                        if not self.flat:
+                            continue
+                        last = k + 1 == len(self.stages)
+                        if last or k in launched:
+                            # stage k's gradients are complete: pack the bucket(s) finished so far into the flat buffer
+                            # INSIDE the graph (one cat kernel), then -- unless this is the end of the step -- an external
+                            # event-record node the side stream will wait for after the launch
+                            opt.pack_stages(lo, k + 1)
+                            if not last:
+                                self._events[k] = _lib.ExternalEvent()
+                                self._events[k].record(self.stream)
+                                self._ranges[k] = (lo, k + 1)
+                            lo = k + 1
                 self._plan.append((g, group))
         self._graphs = [g for g, _ in self._plan]
         # the gradient tensors the replays write (graph-pool memory): `.grad` must point at them whenever the optimiser
@@ -302,17 +335,56 @@ class StagedStep:
         self.static_target.copy_(target, non_blocking=True)
         for p, g in self._captured_grads:
             p.grad = g
-        lo = 0
+        tr = self.host_times
+        t = time.perf_counter() if tr is not None else 0.0
         for i, (g, group) in enumerate(self._plan):
             if i:
                 opt.wait_exchange()                     # exclusive policy: nothing in flight while this graph runs
             g.replay()
+            if tr is not None:
+                t = self._lap(tr, 'replay', t)
             for k in group:
-                if k in self._events:                   # bucket(s) up to stage k: pack + all-reduce on the side stream
-                    opt.exchange_stages(lo, k + 1, after=self._events[k], overlap=True)
-                    lo = k + 1
-        opt.step()
+                if k in self._events:                   # the bucket(s) packed behind stage k: all-reduce on the side stream
+                    lo, hi = self._ranges[k]
+                    if self.host_waits:
+                        # Hold the HOST until the graph has passed the event, then enqueue the collective: a stream-side
+                        # wait that sits in a second hardware queue for half a step slows every dispatch of the replayed
+                        # graph next to it (+160 us per step for ResNet18 V1, +560 us for the V2 shard with twice the
+                        # dispatches; profiles/r03_ddp_rehearsal*.jsonl).  The host has nothing else to do meanwhile: what
+                        # it still has to enqueue for this step and the next takes ~0.3 ms, the graph runs for 2-3 ms more.
+                        self._events[k].synchronize()
+                    opt.exchange_stages(lo, hi, after=self._events[k], overlap=True, packed=True)
+            if tr is not None:
+                t = self._lap(tr, 'buckets', t)
+        if self.flat:
+            opt.rest_is_packed = True                   # the graph packed the remaining buckets too (true for THIS step only:
+        try:                                            # an eager step in between -- a ragged batch -- packs for itself)
+            opt.step()
+        finally:
+            if self.flat:
+                opt.rest_is_packed = False
+        if tr is not None:
+            self._lap(tr, 'step', t)
         return self.outputs
+
+    @staticmethod
+    def _lap(tr, key, t0):
+        t1 = time.perf_counter()
+        tr[key] = tr.get(key, 0.0) + (t1 - t0)
+        tr['calls_' + key] = tr.get('calls_' + key, 0) + 1
+        return t1
+
+    def close(self):
+        """Drop the captured graphs, THEN the external events their event-record nodes refer to (an event must outlive
+        every graph that records it)."""
+        self._plan, self._graphs = [], None
+        self._events = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def describe(self):
         sizes = self.optimizer.bucket_bytes() if self.flat else []

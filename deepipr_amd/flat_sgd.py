@@ -114,6 +114,8 @@ class FlatSGD(torch.optim.Optimizer):
         self._hooks = []
         self._paused = False
         self._side = None                 # side stream of the staged exchange (pack + all-reduce off the main stream)
+        self._side_busy = False
+        self.rest_is_packed = False       # staged mode: the driver packed the last stages' buckets itself (captured)
         self.exposed_events = None        # staged mode, optional: [(start, stop)] events around the exposed exchange
         if self.comm and len(self._buckets) > 1:
             for p, _ in self._slots[:self._buckets[-1][0]]:          # every bucket but the last
@@ -217,11 +219,19 @@ class FlatSGD(torch.optim.Optimizer):
     def bucket_bytes(self):
         return [4 * (self._range(b)[1] - self._range(b)[0]) for b in range(len(self._buckets))]
 
-    def exchange_stages(self, lo, hi, after=None, overlap=True):
+    def pack_stages(self, lo, hi):
+        """Gradients of buckets lo..hi-1 -> their slots of the flat gradient buffer, on the current stream (one `cat`
+        kernel).  The staged stepper CAPTURES this call right behind the stage that finished those gradients, so that
+        the side stream only has to run the collective."""
+        if lo < hi:
+            self._pack_slots(self._buckets[lo][0], self._buckets[hi - 1][1])
+
+    def exchange_stages(self, lo, hi, after=None, overlap=True, packed=False):
         """Staged mode: pack the gradients of buckets lo..hi-1 into the flat gradient buffer and all-reduce that
         range as ONE message.  overlap=True: on a side stream that first waits for the event `after` (recorded on the
         main stream behind the stage that finished these gradients), so the main stream can go on with the next
-        stage; the all-reduce is waited for in step() (or by wait_exchange()).  overlap=False: on the current stream."""
+        stage; the all-reduce is waited for in step() (or by wait_exchange()).  overlap=False: on the current stream.
+        packed=True: the range was packed already (pack_stages, captured in the stage's graph): collective only."""
         if lo >= hi:
             return
         cuda = self.flat_grad.is_cuda
@@ -229,10 +239,16 @@ class FlatSGD(torch.optim.Optimizer):
         end = self._range(hi - 1)[1]
 
         def go():
-            self._pack_slots(self._buckets[lo][0], self._buckets[hi - 1][1])
+            # pack (unless the stage's graph did it) + all-reduce as ORDINARY (async_op=False) operations of whichever
+            # stream is current: the bucket travels on the side stream itself.  An async collective runs on the process
+            # group's own stream behind two more cross-stream hand-offs: for the LAST bucket, which nothing overlaps
+            # with, that measured +150 us per step (one MI355X, exchange forced on in a world of one,
+            # profiles/r03_probe2.json); for the overlapped buckets the async form measured slower as well
+            # (profiles/r03_ddp_rehearsal_async_buckets.jsonl).
+            if not packed:
+                self._pack_slots(self._buckets[lo][0], self._buckets[hi - 1][1])
             if self.comm:
-                w = dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._works.append(w)
+                dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group)
         if cuda and overlap:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.flat_grad.device)
@@ -242,19 +258,21 @@ class FlatSGD(torch.optim.Optimizer):
                 self._side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
             with torch.cuda.stream(self._side):
                 go()
+            self._side_busy = True
         else:
             go()
         for b in range(lo, hi):
             self._launched[b] = True
 
     def wait_exchange(self):
-        """Make the current stream wait for every all-reduce launched so far (the packs run on the same side stream in
-        front of them).  NCCL/RCCL: a stream-side wait, the host does not block."""
+        """Make the current stream wait for everything exchange_stages() put on the side stream (a stream-side wait:
+        the host does not block)."""
         for w in self._works:
             w.wait()
         self._works = []
-        if self._side is not None:
+        if self._side is not None and self._side_busy:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+            self._side_busy = False
 
     def _on_grad(self, param):
         if self._paused or self._mode != 'hooks':
@@ -302,7 +320,7 @@ class FlatSGD(torch.optim.Optimizer):
             if rest:                                      # stages nobody exchanged yet: one message, current stream
                 if rest != list(range(rest[0], len(self._buckets))):
                     raise RuntimeError('FlatSGD: staged exchange must proceed in stage order')
-                self.exchange_stages(rest[0], len(self._buckets), overlap=False)
+                self.exchange_stages(rest[0], len(self._buckets), overlap=False, packed=self.rest_is_packed)
             self.wait_exchange()
             if timed:
                 ev1 = torch.cuda.Event(enable_timing=True)

@@ -49,6 +49,8 @@ int deepipr_event_create(void **event);
 int deepipr_event_destroy(void *event);
 int deepipr_event_record(void *event, void *stream);
 int deepipr_stream_wait_event(void *stream, void *event);
+/* Block the calling HOST thread until the event's latest record has completed (hipEventSynchronize). */
+int deepipr_event_synchronize(void *event);
 
 /* Opt-in in-situ timing (the one piece of process-global state, off by default): while enabled every
  * kernel below is dispatched through hipExtLaunchKernelGGL with a start and a stop hipEvent attached to

@@ -359,3 +359,10 @@ def test_external_event_of_a_captured_graph_orders_a_side_stream(K):
         # (not asserted: `done` usually still holds a value below 4 * i -- the side stream ran ahead of the graph's tail)
         assert float(done.max()) <= 4.0 * i
     torch.cuda.synchronize()
+    # the host-side wait (what staged.py uses before it enqueues a bucket's collective): after it, what the graph did
+    # before the node is visible to a plain read on ANY stream
+    for i in range(31, 41):
+        g.replay()
+        ev.synchronize()
+        assert bool((big[:: 1 << 12] == float(i)).all()), i
+    torch.cuda.synchronize()

@@ -87,7 +87,8 @@ def main():
             net, opt = fresh()
             st = S.StagedStep(fn, net, opt, x, y, graph=True)
             if noxchg:
-                st._events = {}                    # captured event nodes stay; nothing is launched behind them
+                st._unused_events, st._events = st._events, {}    # the captured event nodes stay (and their events must
+                # outlive the graph); nothing is launched behind them
                 st._after_stage = lambda k: None
                 st._before_stage = lambda k: None
             measure('staged-%d%s' % (len(st.stages), '-noxchg' if noxchg else ''), lambda: st(x, y))

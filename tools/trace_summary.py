@@ -17,6 +17,7 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--top', type=int, default=25)
+    ap.add_argument('--out-csv', default=None, help='also write kernel name, calls/step, us/step to this CSV')
     ap.add_argument('--gaps', type=int, default=0, help='also list the N largest idle gaps between consecutive kernels')
     ap.add_argument('--marker', default=None, help='once-per-step kernel (default: k_ce_finish, else nll_loss_forward)')
     args = ap.parse_args()
@@ -56,6 +57,12 @@ def main():
         print('| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.2f |' %
               (short, len(v) / args.steps, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3,
                sum(v) / args.steps / 1e3, 100.0 * sum(v) / busy))
+    if args.out_csv:
+        with open(args.out_csv, 'w') as f:
+            w = csv.writer(f)
+            w.writerow(['kernel', 'calls_per_step', 'us_per_step'])
+            for n, v in order:
+                w.writerow([n[:160], round(len(v) / args.steps, 2), round(sum(v) / args.steps / 1e3, 2)])
     if args.gaps:
         gaps(win, args.steps, args.gaps)
 
