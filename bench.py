@@ -339,24 +339,65 @@ def main():
     # --eager: eager dispatch with the exchange overlapped with backward; --ddp: DistributedDataParallel (eager).
     eager_step = step
     use_graph = not args.eager and not args.ddp
+    import torch.distributed as tdist
+    fn = train_step_v1 if args.scheme == 1 else train_step_v23
+    graphed, launch_form = None, 'eager'
+
+    def everyone(ok):
+        """True only if `ok` on EVERY rank: the ranks must take the same launch form (their collectives pair up)."""
+        if not (tdist.is_available() and tdist.is_initialized()):
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
+    def build(form):
+        if form == 'staged':
+            # data parallel: backward cut into stages at the gradient buckets' boundaries, captured back to back;
+            # bucket k's RCCL all-reduce on a side stream while stage k + 1 replays (experiments/staged.py)
+            from deepipr_amd.experiments.staged import StagedStep
+            return StagedStep(fn, net, opt, xs[0], ys[0], graph=True)
+        from deepipr_amd.experiments.graph_step import GraphedTrainStep
+        return GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
+
+    forms = []
     if use_graph:
+        forms = ['staged', 'unstaged'] if (tdist.is_initialized() and not args.unstaged) else ['unstaged']
+    # state to return to if a launch form has to be given up after it already ran steps (N > 1 only)
+    keep = None
+    if len(forms) > 1:
+        keep = ({k: v.clone() for k, v in model.state_dict().items()}, opt.flat_buf.clone())
+    use_graph = False
+    for form in forms:
+        err = None
         try:
-            from deepipr_amd.experiments.graph_step import GraphedTrainStep
-            fn = train_step_v1 if args.scheme == 1 else train_step_v23
-            import torch.distributed as tdist
-            if tdist.is_initialized() and not args.unstaged:
-                # data parallel: backward cut into stages at the gradient buckets' boundaries, one hipGraph per stage,
-                # bucket k's RCCL all-reduce on a side stream while stage k + 1 replays (experiments/staged.py)
-                from deepipr_amd.experiments.staged import StagedStep
-                graphed = StagedStep(fn, net, opt, xs[0], ys[0], graph=True)
-            else:
-                graphed = GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
-            step = lambda i: graphed(xs[i % nb], ys[i % nb])
-        except Exception as exc:                           # capture refused: measure the eager step instead
-            print('bench.py: hipGraph capture failed (%s: %s); timing the eager step' % (type(exc).__name__, exc),
-                  file=sys.stderr)
-            torch.cuda.synchronize()
-            use_graph, step = False, eager_step
+            graphed = build(form)
+            step = lambda i, g=graphed: g(xs[i % nb], ys[i % nb])
+            if form == 'staged':
+                # a few replays before the form is accepted: an in-launch exchange that timed out next to a collective
+                # (never seen; staged.py explains why it should not happen) would show here, on any rank
+                for i in range(3):
+                    step(i)
+                torch.cuda.synchronize()
+                if _exchange_timeouts():
+                    raise RuntimeError('in-launch exchange timed out next to a collective')
+        except Exception as exc:                           # capture refused / form unusable
+            err = exc
+        if everyone(err is None):
+            use_graph, launch_form = True, form
+            break
+        print('bench.py: launch form %r given up (%s); trying the next one' % (
+            form, 'another rank failed' if err is None else '%s: %s' % (type(err).__name__, err)), file=sys.stderr)
+        torch.cuda.synchronize()
+        if hasattr(graphed, 'close'):
+            graphed.close()
+        graphed, step = None, eager_step
+        if keep is not None:
+            with torch.no_grad():
+                model.load_state_dict(keep[0])
+                opt.flat_buf.copy_(keep[1])
+            from deepipr_amd.passport_ops import kernels as _k
+            _k.reset_sync_words()
     import torch.distributed as _td
     tdist_on = _td.is_available() and _td.is_initialized()
     note('launch mode: %s' % ('hipGraph replay' if use_graph else 'eager'))
@@ -456,8 +497,9 @@ def main():
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': (('hipGraph replay of %s; kernel timing from %d eager steps right after the timed region'
                                % ('the whole step' if not tdist_on else ('zero_grad..backward, then one eager '
-                                  'all-reduce + fused SGD' if args.unstaged else 'the staged step (one graph per '
-                                  'backward stage, bucket all-reduces in between, fused SGD)'), sampled))
+                                  'all-reduce + fused SGD' if launch_form == 'unstaged' else 'the staged step '
+                                  '(backward stages captured back to back, bucket all-reduces on a side stream '
+                                  'behind each stage\'s event, fused SGD)'), sampled))
                               if use_graph else 'eager')},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',

@@ -729,17 +729,69 @@ def _conv_fwd(x_in, w, stride, pad):
     return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
 
 
-def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m):
+def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     """Backward of the data convolution that ran inside a fused passport node: MIOpen's dgrad / wgrad, then the passport
-    branch's rank-2 update added INTO that wgrad (deepipr_gamma_beta_bwd_acc).  -> dx_in, dW."""
+    branch's rank-2 update added INTO that wgrad (deepipr_gamma_beta_bwd_acc) -- or, with `defer` = (share, index), left
+    to the layer group's one launch (_Rank2Group), which is handed the wgrad buffer.  -> dx_in, dW."""
     need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     if not (need_dx or need_dw):                      # frozen first layer: nothing flows further
         return None, None
     dx, dw, _ = torch.ops.aten.convolution_backward(
         dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
     if need_dw:
-        dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw.contiguous())
+        dw = dw.contiguous()
+        if defer is not None:
+            defer[0].wgrads[defer[1]] = dw
+        else:
+            dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw)
     return dx, dw
+
+
+class _Rank2Share:
+    """What the layers of one _Rank2Group leave for it during backward: MIOpen's wgrad buffer per layer."""
+    __slots__ = ('wgrads',)
+
+    def __init__(self):
+        self.wgrads = {}
+
+
+class _Rank2Group(torch.autograd.Function):
+    """The passport branch's weight gradient of SEVERAL layers in one launch (deepipr_gamma_beta_bwd_multi).
+
+    Forward is bookkeeping only: the gamma / beta pairs the batched GEMV launch already produced (gamma_beta_batch) are
+    handed out as outputs of this node, so that autograd knows they come from the layers' weights.  Each layer's fused
+    node takes its pair as gamma_in / beta_in, and in backward returns dgamma / dbeta (sign-loss gradient included)
+    for them instead of launching its own rank-2 update; it leaves MIOpen's wgrad buffer of its weight with the share.
+    This node's backward runs when ALL its layers have been through backward (autograd's dependency count) and adds
+    dgamma_i (x) m_scale_i + dbeta_i (x) m_bias_i INTO those buffers in one launch.  It returns no gradient of its
+    own: the weights' AccumulateGrad nodes wait for both of a weight's consumers (the layer node and this one) and
+    then see the layer node's buffer, complete.  ResNet18: 5 launches of 4-6 us -> one of ~11 us for 67 MB
+    (profiles/r03_gemv_bench.json).  A group never spans two backward stages of the staged step (gamma_beta_batch)."""
+
+    @staticmethod
+    def forward(ctx, share, ms, pairs, *weights):
+        ctx.share, ctx.ms, ctx.n = share, ms, len(weights)
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for pair in pairs for t in pair)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        share, dgs, dbs, ms, dws = ctx.share, [], [], [], []
+        for i in range(ctx.n):
+            dg, db = grads[2 * i], grads[2 * i + 1]
+            if dg is None and db is None:
+                continue                                   # this layer took no part (or did its own update)
+            dw = share.wgrads.pop(i, None)
+            if dw is None or dg is None or db is None:
+                raise RuntimeError('deepipr_amd: rank-2 group: layer %d sent dgamma / dbeta without its wgrad buffer' % i)
+            dgs.append(dg.contiguous())
+            dbs.append(db.contiguous())
+            ms.append(ctx.ms[i])
+            dws.append(dw)
+        share.wgrads.clear()
+        if dws:
+            kernels.gamma_beta_bwd_multi(dgs, dbs, ms, dws, accumulate=True)
+        return (None, None, None) + (None,) * ctx.n
 
 
 class _PassportLayer(torch.autograd.Function):
@@ -802,7 +854,8 @@ class _PassportBNLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, residual, cfg):
-        alpha, relu, stride, pad, training, momentum, eps, conv = cfg
+        alpha, relu, stride, pad, training, momentum, eps, conv = cfg[:8]
+        ctx.defer = cfg[8] if len(cfg) > 8 else None     # (Rank2Group share, index): see _Rank2Group
         x = x.contiguous()
         w = None if weight is None else weight.contiguous()
         x_in = None
@@ -856,17 +909,24 @@ class _PassportBNLayer(torch.autograd.Function):
                                       dy2=None if dy2 is None else dy2.contiguous(), tail_out=tail_out)
         dx, dw, dg, db = out[:4]
         dres = out[4] if ctx.tail else None
+        deferred = False
         if in_node_conv:
-            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m)
+            # the rank-2 update of several layers in ONE launch: this node hands MIOpen's wgrad and dgamma / dbeta to
+            # the group node (_Rank2Group), which runs once all its layers have been here
+            deferred = (ctx.defer is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[4]
+                        and ctx.needs_input_grad[5])
+            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m, defer=ctx.defer if deferred else None)
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
+        own = w is None or deferred                       # dgamma / dbeta travel on to whoever produced gamma_in / beta_in
         return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
-                dg if w is None else None, db if w is None else None, None, None, None, None, None, dres, None)
+                dg if own else None, db if own else None, None, None, None, None, None, dres, None)
 
 
-def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual, conv=None):
-    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps, conv)
+def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual, conv=None,
+              defer=None):
+    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps, conv, defer)
     return _PassportBNLayer.apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked if bn.training else None, residual, cfg)
 
@@ -876,11 +936,13 @@ def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, 
     """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False).
     conv_inside: `x` is the layer's INPUT; the data convolution runs inside the node and the shared weight's
     gradient is accumulated in place (see _PassportBNLayer).
-    pre = (gamma, beta) already computed for this weight by the batched GEMV launch (gamma_beta_batch).
+    pre = (gamma, beta[, share, index]) already computed for this weight by the batched GEMV launch (gamma_beta_batch);
+    with share / index the rank-2 weight gradient is left to the layer group's launch (_Rank2Group).
     -> y, gamma, beta, loss, acc, bits; with `residual` y is the PAIR of handles of relu(layer + residual)."""
-    pg, pb = pre if pre is not None else (None, None)
+    pg, pb = pre[:2] if pre is not None else (None, None)
+    defer = tuple(pre[2:4]) if (pre is not None and len(pre) >= 4 and conv_inside) else None
     y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, pg, pb, b, m, bn, alpha, relu, stride,
-                                                    pad, residual, (stride, pad) if conv_inside else None)
+                                                    pad, residual, (stride, pad) if conv_inside else None, defer)
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
@@ -889,11 +951,14 @@ class gamma_beta_batch:
     form in ONE launch (deepipr_gamma_beta_fwd_multi) instead of one GEMV launch per layer -- ResNet18: the five
     layer4 weights, 33.6 MB streamed once by a launch that fills the chip.  They depend only on the weights and the
     cached pooled keys, so they are computed up front; each layer picks its pair up (PassportLayerBase._gb_pre) and its
-    autograd node treats it as its own GEMV's result (backward: the rank-2 update into the shared weight's gradient, as
-    before).  Pairs nobody used are dropped on exit.  DEEPIPR_NO_GEMV_BATCH=1 switches the batching off."""
+    autograd node treats it as its own GEMV's result.  Backward: the layers of one GROUP (`group_of(layer)`: the
+    backward stage the layer belongs to, models' backward_stages(); one group without it) leave the rank-2 update of
+    the shared weights' gradients to one launch per group (_Rank2Group); a layer alone in its group, or whose
+    convolution runs outside the fused node, does its own as before.  Pairs nobody used are dropped on exit.
+    DEEPIPR_NO_GEMV_BATCH=1 switches the batching off, DEEPIPR_NO_RANK2_BATCH=1 only the backward part."""
 
-    def __init__(self, layers, force_passport=False, ind=0):
-        self.layers, self.args, self.used = layers, (force_passport, ind), []
+    def __init__(self, layers, force_passport=False, ind=0, group_of=None):
+        self.layers, self.args, self.used, self.group_of = layers, (force_passport, ind), [], group_of
 
     def __enter__(self):
         if os.environ.get('DEEPIPR_NO_GEMV_BATCH') == '1':
@@ -903,6 +968,7 @@ class gamma_beta_batch:
             r = m.batched_gamma_beta_request(*self.args)
             if r is not None:
                 reqs.append((m, r))
+        grouped = torch.is_grad_enabled() and os.environ.get('DEEPIPR_NO_RANK2_BATCH') != '1'
         for lo in range(0, len(reqs), _lib.GEMV_MAX_LAYERS):
             chunk = reqs[lo:lo + _lib.GEMV_MAX_LAYERS]
             if len(chunk) < 2:
@@ -910,8 +976,21 @@ class gamma_beta_batch:
             with torch.no_grad():
                 pairs = kernels.gamma_beta_fwd_multi([w.detach().contiguous() for _, (w, _m) in chunk],
                                                      [mm for _, (_w, mm) in chunk])
-            for (m, _r), pair in zip(chunk, pairs):
-                m._gb_pre = pair
+            groups = {}
+            for idx, (m, (w, _mm)) in enumerate(chunk):
+                if grouped and w.requires_grad:
+                    groups.setdefault(self.group_of(m) if self.group_of is not None else 0, []).append(idx)
+            pre = {idx: pairs[idx] for idx in range(len(chunk))}
+            for members in groups.values():
+                if len(members) < 2:
+                    continue
+                share = _Rank2Share()
+                outs = _Rank2Group.apply(share, [chunk[i][1][1] for i in members], [pairs[i] for i in members],
+                                         *[chunk[i][1][0] for i in members])
+                for j, i in enumerate(members):
+                    pre[i] = (outs[2 * j], outs[2 * j + 1], share, j)
+            for idx, (m, _r) in enumerate(chunk):
+                m._gb_pre = pre[idx]
                 self.used.append(m)
         return self
 
@@ -919,6 +998,21 @@ class gamma_beta_batch:
         for m in self.used:
             m._gb_pre = None
         return False
+
+
+def stage_groups(model):
+    """layer -> index of the backward stage (model.backward_stages()) it belongs to: the `group_of` of
+    gamma_beta_batch.  Cached on the model."""
+    cached = model.__dict__.get('_stage_of')
+    table = cached[1] if (cached is not None and cached[0] == id(model)) else None     # a deep copy carries stale ids
+    if table is None:
+        table = {}
+        for k, (_cut, mods) in enumerate(model.backward_stages()):
+            for mod in mods:
+                for sub in mod.modules():
+                    table.setdefault(id(sub), k)
+        model.__dict__['_stage_of'] = (id(model), table)
+    return lambda layer: table.get(id(layer), -1)
 
 
 def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False):

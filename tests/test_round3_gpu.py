@@ -366,3 +366,78 @@ def test_external_event_of_a_captured_graph_orders_a_side_stream(K):
         ev.synchronize()
         assert bool((big[:: 1 << 12] == float(i)).all()), i
     torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- rank-2 update of a layer group in one launch
+@pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2', 'alexnet_v1'])
+def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_kind, monkeypatch):
+    """The passport branch's dW of a group of layers in ONE launch (_Rank2Group, the default) against one launch per
+    layer (DEEPIPR_NO_RANK2_BATCH=1) and against no batching at all (DEEPIPR_NO_GEMV_BATCH=1): logits and every
+    parameter gradient bit-identical with MIOpen pinned; the launch counts say which form ran.  The AlexNet's passport
+    layers span two backward stages (features 4 | 5, 6): the groups follow the stages."""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from oracle.cases import alexnet_config, resnet18_config
+    private = net_kind.endswith('v2')
+    if net_kind.startswith('resnet18'):
+        from deepipr_amd.models.resnet_passport import ResNet18Passport
+        from deepipr_amd.models.resnet_passport_private import ResNet18Private
+        cfg, ctor, n = resnet18_config(), (ResNet18Private if private else ResNet18Passport), 32
+    else:
+        from deepipr_amd.models.alexnet_passport import AlexNetPassport
+        cfg, ctor, n = alexnet_config(), AlexNetPassport, 64
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': 0.1})
+    torch.manual_seed(3)
+    np.random.seed(3)
+    if net_kind.startswith('resnet18'):
+        net = ctor(num_classes=10, passport_kwargs=kw).to(DEV)
+    else:
+        net = ctor(3, 10, kw).to(DEV)
+    net.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (n,), generator=g).to(DEV)
+    with torch.no_grad():
+        net(x)                                                # keys
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    ce = torch.nn.functional.cross_entropy
+
+    def step(env):
+        for k in ('DEEPIPR_NO_RANK2_BATCH', 'DEEPIPR_NO_GEMV_BATCH'):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, '1')
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        _lib.profile_enable(True)
+        if private:
+            outs = [net(x, ind=0), net(x, ind=1)]
+            loss = ce(outs[0], y) + ce(outs[1], y) + sum(m.sign_loss_private.loss for m in net.modules()
+                                                         if hasattr(m, 'sign_loss_private'))
+        else:
+            outs = [net(x)]
+            loss = ce(outs[0], y) + sum(m.sign_loss.loss for m in net.modules()
+                                        if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+        loss.backward()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        got = {'logits%d' % i: o.detach().clone() for i, o in enumerate(outs)}
+        got.update({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        return got, int(prof['gamma_beta_fwd'][1]), int(prof['gamma_beta_bwd'][1])
+
+    with pinned_miopen():
+        grouped, f0, b0 = step(())
+        per_layer, f1, b1 = step(('DEEPIPR_NO_RANK2_BATCH',))
+        unbatched, f2, b2 = step(('DEEPIPR_NO_GEMV_BATCH',))
+    n_layers = {'resnet18_v1': 5, 'resnet18_v2': 5, 'alexnet_v1': 3}[net_kind]
+    fwd_passes = 1                                              # V2: only the private pass (ind = 1) uses the passports
+    assert (f1, b1) == (fwd_passes, n_layers * fwd_passes), (f1, b1)
+    assert (f2, b2) == (n_layers * fwd_passes, n_layers * fwd_passes), (f2, b2)
+    # one launch per group: ResNet18's five layers are one stage; AlexNet: features 5, 6 together, features 4 alone
+    assert (f0, b0) == (fwd_passes, {'resnet18_v1': 1, 'resnet18_v2': 1, 'alexnet_v1': 2}[net_kind]), (f0, b0)
+    for name, other in (('per layer', per_layer), ('unbatched', unbatched)):
+        assert set(other) == set(grouped)
+        diff = {k: float((grouped[k] - other[k]).abs().max()) for k in grouped if not torch.equal(grouped[k], other[k])}
+        assert not diff, '%s: %d tensors differ: %s' % (name, len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:4])
