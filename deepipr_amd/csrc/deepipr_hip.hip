@@ -1958,6 +1958,272 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
 }
 
 // ============================================================================================
+// A projection block's LAST TWO norm layers and its tail in one launch per direction
+// (models/resnet_passport.py:67-85: out = relu(bn_2(conv_2(h)) + bn_s(conv_s(x))) with a 1x1 stride-2 shortcut conv).
+// The two norm layers are independent until the add, have the same shape and both own their channels the same way,
+// so one workgroup keeps its slice of BOTH conv outputs in registers:
+//   forward   read a, b; write out                     12 B/elt  (separate launches: 8 for the shortcut layer + 12
+//                                                                 for the tail-folded layer = 20, and one launch more)
+//   backward  read dy (+ dy2), out, a, b; write da, db  28 B/elt  (separate: 24 + 12 = 36): the masked gradient
+//                                                                 d = (dy + dy2)[out > 0] never leaves the registers
+// Same plan, same unit -> thread mapping, same reduction order and the same per-element arithmetic as the separate
+// kernels: results are bit-identical to them (tests/test_round3_gpu.py).  W-less form only (learnable gamma / beta:
+// plain ConvBlocks), batch statistics, no inner ReLU.  S > 1: the second layer's partial sums are exchanged through
+// the slots of channel index cb + C (never used by a split launch of C channels: a region has 256 slots, a launch
+// splits at most 256 / S of them).
+// ============================================================================================
+struct DualFwdArgs {
+    const float4 *xb;
+    const float *gamma_b, *beta_b;
+    float momentum_b, eps_b;
+    float *running_mean_b, *running_var_b;
+    long long *num_batches_tracked_b;
+    float *tbl_b;
+};
+
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_dual_fwd(
+    const float4 *__restrict__ xa, float4 *__restrict__ y, const float *__restrict__ gamma_a,
+    const float *__restrict__ beta_a, int N, int C, ResPlan pl, BnFinishArgs f, DualFwdArgs d, unsigned *sync) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[4];
+    const int t = threadIdx.x;
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    const int c0 = pl.c_off + cb * pl.G;
+    const int n0 = s * pl.nps;
+    const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
+    const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    ResXch xca{}, xcb{};
+    if (pl.S > 1) {
+        xca = res_xch_begin(sync, cb, s, pl.S);
+        xcb = res_xch_begin(sync, cb + C, s, pl.S);
+    }
+    const int c_mine = c0 + c_local;
+    const float ga = gamma_a[c_mine], ba = beta_a[c_mine], gb = d.gamma_b[c_mine], bb = d.beta_b[c_mine];
+    const bool owner = s == 0 && t < pl.gq && t == c_local * pl.q4;
+    float rma = 0.0f, rva = 0.0f, rmb = 0.0f, rvb = 0.0f;
+    if (owner && f.running_mean) {
+        rma = f.running_mean[c_mine];
+        rva = f.running_var[c_mine];
+    }
+    if (owner && d.running_mean_b) {
+        rmb = d.running_mean_b[c_mine];
+        rvb = d.running_var_b[c_mine];
+    }
+    const size_t k_at = static_cast<size_t>(c_mine) * pl.q4 * 4;
+    const float Ka = reinterpret_cast<const float *>(xa)[k_at], Kb = reinterpret_cast<const float *>(d.xb)[k_at];
+    float4 va[F4], vb[F4];
+    unsigned idx[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        va[k] = make_float4(Ka, Ka, Ka, Ka);
+        vb[k] = make_float4(Kb, Kb, Kb, Kb);
+        idx[k] = 0;
+        if (j < units) {
+            const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
+            idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
+            va[k] = xa[idx[k]];
+            vb[k] = d.xb[idx[k]];
+        }
+    }
+    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const float p0 = va[k].x - Ka, p1 = va[k].y - Ka, p2 = va[k].z - Ka, p3 = va[k].w - Ka;
+        a0 += (p0 + p1) + (p2 + p3);
+        a1 = fmaf(p0, p0, a1);
+        a1 = fmaf(p1, p1, a1);
+        a1 = fmaf(p2, p2, a1);
+        a1 = fmaf(p3, p3, a1);
+        const float q0 = vb[k].x - Kb, q1 = vb[k].y - Kb, q2 = vb[k].z - Kb, q3 = vb[k].w - Kb;
+        b0 += (q0 + q1) + (q2 + q3);
+        b1 = fmaf(q0, q0, b1);
+        b1 = fmaf(q1, q1, b1);
+        b1 = fmaf(q2, q2, b1);
+        b1 = fmaf(q3, q3, b1);
+    }
+    double sa1 = static_cast<double>(a0), sa2 = static_cast<double>(a1);
+    double sb1 = static_cast<double>(b0), sb2 = static_cast<double>(b1);
+    res_block_sums<T>(sa1, sa2, pl, c_local, red);
+    res_block_sums<T>(sb1, sb2, pl, c_local, red);
+    if (pl.S > 1) {                                   // G == 1 here
+        if (t < kWave) {
+            res_exchange(sa1, sa2, xca, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
+            res_exchange(sb1, sb2, xcb, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
+            if (t == 0) {
+                xch[0] = sa1;
+                xch[1] = sa2;
+                xch[2] = sb1;
+                xch[3] = sb2;
+            }
+        }
+        __syncthreads();
+        sa1 = xch[0];
+        sa2 = xch[1];
+        sb1 = xch[2];
+        sb2 = xch[3];
+    }
+    const double dmua = sa1 * f.inv_m, dmub = sb1 * f.inv_m;
+    double vara = sa2 * f.inv_m - dmua * dmua, varb = sb2 * f.inv_m - dmub * dmub;
+    if (vara < 0.0) vara = 0.0;
+    if (varb < 0.0) varb = 0.0;
+    const float mean_a = static_cast<float>(static_cast<double>(Ka) + dmua);
+    const float mean_b = static_cast<float>(static_cast<double>(Kb) + dmub);
+    const float inv_a = static_cast<float>(1.0 / sqrt(vara + static_cast<double>(f.eps)));
+    const float inv_b = static_cast<float>(1.0 / sqrt(varb + static_cast<double>(d.eps_b)));
+    const float4 cha = make_float4(mean_a, inv_a, ga, ba), chb = make_float4(mean_b, inv_b, gb, bb);
+    if (owner) {
+        if (f.running_mean) {
+            f.running_mean[c_mine] = (1.0f - f.momentum) * rma + f.momentum * mean_a;
+            f.running_var[c_mine] = (1.0f - f.momentum) * rva + f.momentum * static_cast<float>(vara * f.unbias);
+        }
+        if (d.running_mean_b) {
+            d.running_mean_b[c_mine] = (1.0f - d.momentum_b) * rmb + d.momentum_b * mean_b;
+            d.running_var_b[c_mine] = (1.0f - d.momentum_b) * rvb + d.momentum_b * static_cast<float>(varb * f.unbias);
+        }
+        float4 *row = reinterpret_cast<float4 *>(f.tbl + static_cast<size_t>(c_mine) * kTbl);
+        row[0] = cha;
+        row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        row = reinterpret_cast<float4 *>(d.tbl_b + static_cast<size_t>(c_mine) * kTbl);
+        row[0] = chb;
+        row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        if (f.num_batches_tracked) *f.num_batches_tracked += 1;
+        if (d.num_batches_tracked_b) *d.num_batches_tracked_b += 1;
+    }
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        if (j < units) {
+            const float4 o = make_float4(bn_affine1<false>(va[k].x, cha), bn_affine1<false>(va[k].y, cha),
+                                         bn_affine1<false>(va[k].z, cha), bn_affine1<false>(va[k].w, cha));
+            const float4 r = make_float4(bn_affine1<false>(vb[k].x, chb), bn_affine1<false>(vb[k].y, chb),
+                                         bn_affine1<false>(vb[k].z, chb), bn_affine1<false>(vb[k].w, chb));
+            y[idx[k]] = make_float4(relu1(o.x + r.x), relu1(o.y + r.y), relu1(o.z + r.z), relu1(o.w + r.w));
+        }
+    }
+}
+
+struct DualBwdArgs {
+    const float4 *dy2;            // second incoming gradient of the block's output, may be nullptr
+    const float4 *out;            // the block's output (mask of the outer ReLU)
+    const float4 *xb;
+    const float *tbl_b;
+    float4 *dxb;
+    float *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
+    double inv_m;
+};
+
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_dual_bwd(
+    const float4 *__restrict__ dy, const float4 *__restrict__ xa, const float *__restrict__ tbl_a,
+    float4 *__restrict__ dxa, int N, int C, ResPlan pl, unsigned *sync, DualBwdArgs a) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[4];
+    const int t = threadIdx.x;
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    const int c0 = pl.c_off + cb * pl.G;
+    const int n0 = s * pl.nps;
+    const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
+    const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
+    ResXch xca{}, xcb{};
+    if (pl.S > 1) {
+        xca = res_xch_begin(sync, cb, s, pl.S);
+        xcb = res_xch_begin(sync, cb + C, s, pl.S);
+    }
+    const float4 cha = *reinterpret_cast<const float4 *>(tbl_a + static_cast<size_t>(c0 + c_local) * kTbl);
+    const float4 chb = *reinterpret_cast<const float4 *>(a.tbl_b + static_cast<size_t>(c0 + c_local) * kTbl);
+    float4 dz[F4], ha[F4], hb[F4];
+    unsigned idx[F4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        dz[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ha[k] = make_float4(cha.x, cha.x, cha.x, cha.x);      // -> xhat 0 for the unused units
+        hb[k] = make_float4(chb.x, chb.x, chb.x, chb.x);
+        idx[k] = 0;
+        if (j < units) {
+            const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
+            idx[k] = static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
+            float4 g = dy[idx[k]];
+            ha[k] = xa[idx[k]];
+            hb[k] = a.xb[idx[k]];
+            const float4 o = a.out[idx[k]];
+            if (a.dy2) {
+                const float4 e = a.dy2[idx[k]];
+                g = make_float4(g.x + e.x, g.y + e.y, g.z + e.z, g.w + e.w);
+            }
+            dz[k] = make_float4(o.x > 0.0f ? g.x : 0.0f, o.y > 0.0f ? g.y : 0.0f, o.z > 0.0f ? g.z : 0.0f,
+                                o.w > 0.0f ? g.w : 0.0f);
+        }
+    }
+    float a0 = 0.0f, b0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        ha[k] = make_float4((ha[k].x - cha.x) * cha.y, (ha[k].y - cha.x) * cha.y, (ha[k].z - cha.x) * cha.y,
+                            (ha[k].w - cha.x) * cha.y);
+        hb[k] = make_float4((hb[k].x - chb.x) * chb.y, (hb[k].y - chb.x) * chb.y, (hb[k].z - chb.x) * chb.y,
+                            (hb[k].w - chb.x) * chb.y);
+        a0 = fmaf(dz[k].x, ha[k].x, a0);
+        a0 = fmaf(dz[k].y, ha[k].y, a0);
+        a0 = fmaf(dz[k].z, ha[k].z, a0);
+        a0 = fmaf(dz[k].w, ha[k].w, a0);
+        b0 = fmaf(dz[k].x, hb[k].x, b0);
+        b0 = fmaf(dz[k].y, hb[k].y, b0);
+        b0 = fmaf(dz[k].z, hb[k].z, b0);
+        b0 = fmaf(dz[k].w, hb[k].w, b0);
+        a1 += (dz[k].x + dz[k].y) + (dz[k].z + dz[k].w);
+    }
+    double aga = static_cast<double>(a0), ab = static_cast<double>(a1);
+    double agb = static_cast<double>(b0), ab2 = ab;
+    res_block_sums<T>(aga, ab, pl, c_local, red);
+    res_block_sums<T>(agb, ab2, pl, c_local, red);
+    if (pl.S > 1) {
+        if (t < kWave) {
+            res_exchange(aga, ab, xca, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
+            res_exchange(agb, ab2, xcb, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
+            if (t == 0) {
+                xch[0] = aga;
+                xch[1] = ab;
+                xch[2] = agb;
+                xch[3] = ab2;
+            }
+        }
+        __syncthreads();
+        aga = xch[0];
+        ab = xch[1];
+        agb = xch[2];
+        ab2 = xch[3];
+    }
+    if (s == 0 && t < pl.gq && t == c_local * pl.q4) {
+        const int c = c0 + c_local;
+        a.dgamma_a[c] = static_cast<float>(aga);
+        a.dbeta_a[c] = static_cast<float>(ab);
+        a.dgamma_b[c] = static_cast<float>(agb);
+        a.dbeta_b[c] = static_cast<float>(ab2);
+    }
+    const float c2a = static_cast<float>(ab * a.inv_m), c3a = static_cast<float>(aga * a.inv_m);
+    const float c2b = static_cast<float>(ab2 * a.inv_m), c3b = static_cast<float>(agb * a.inv_m);
+    const float sca = cha.z * cha.y, scb = chb.z * chb.y;
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const int j = t + k * T;
+        if (j < units) {
+            dxa[idx[k]] = make_float4(sca * (dz[k].x - c2a - ha[k].x * c3a), sca * (dz[k].y - c2a - ha[k].y * c3a),
+                                      sca * (dz[k].z - c2a - ha[k].z * c3a), sca * (dz[k].w - c2a - ha[k].w * c3a));
+            a.dxb[idx[k]] = make_float4(scb * (dz[k].x - c2b - hb[k].x * c3b), scb * (dz[k].y - c2b - hb[k].y * c3b),
+                                        scb * (dz[k].z - c2b - hb[k].z * c3b), scb * (dz[k].w - c2b - hb[k].w * c3b));
+        }
+    }
+}
+
+// ============================================================================================
 // GroupNorm / InstanceNorm (affine=False, models/layers/passportconv2d.py:59-62: GroupNorm(o // 16, o),
 // InstanceNorm2d(o)) fused with the passport affine + ReLU, register-resident like k_bn_res_*.
 //

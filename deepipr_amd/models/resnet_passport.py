@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from deepipr_amd import cuts
-from deepipr_amd.models._builders import PASSPORT_TYPES, conv_factory, run_layer, run_layer_tail
+from deepipr_amd.models._builders import ind_matters, shared_trunk, trunk_sharing_enabled, PASSPORT_TYPES, conv_factory, run_layer, run_layer_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.passport_ops import gamma_beta_batch, stage_groups
 
@@ -134,17 +134,52 @@ class ResNetPassport(nn.Module):
     def passport_layers(self):
         return [m for m in self.modules() if isinstance(m, PASSPORT_TYPES)]
 
+    def _blocks(self):
+        return [(li, bi, block) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
+                for bi, block in enumerate(layer)]
+
+    def _run_blocks(self, out, skip, blocks, force_passport, ind, marked=False):
+        for i, (li, bi, block) in enumerate(blocks):
+            if li >= 2 and bi == 0 and not (marked and i == 0):      # the cut points backward_stages() names
+                out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
+            out, skip = block.forward_pair(out, skip, force_passport, ind)
+        return out
+
+    def _head(self, out):
+        out = F.adaptive_avg_pool2d(out, (1, 1))
+        return self.linear(out.view(out.size(0), -1))
+
     def forward(self, x, force_passport=False, ind=0):
         # gamma / beta of all passport layers in one GEMV launch, up front (they depend on weights and keys only)
         with gamma_beta_batch(self.passport_layers() if x.is_cuda else (), force_passport, ind, stage_groups(self)):
             out, skip = self._stem(x, force_passport, ind)
-            for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
-                for bi, block in enumerate(layer):
-                    if li >= 2 and bi == 0:                      # the cut points backward_stages() names
-                        out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
-                    out, skip = block.forward_pair(out, skip, force_passport, ind)
-        out = F.adaptive_avg_pool2d(out, (1, 1))
-        return self.linear(out.view(out.size(0), -1))
+            out = self._run_blocks(out, skip, self._blocks(), force_passport, ind)
+        return self._head(out)
+
+    def forward_dual(self, x, force_passport=False):
+        """-> (self(x, ind=0), self(x, ind=1)), the two forward passes of a V2 / V3 step (trainer_private.py:159-171),
+        with everything in front of the first private passport layer run ONCE (_builders.shared_trunk)."""
+        blocks = self._blocks()
+        split = next((i for i, (_l, _b, blk) in enumerate(blocks) if ind_matters(blk)), len(blocks))
+        trunk = [self.convbnrelu_1] + [blk for _l, _b, blk in blocks[:split]]
+        if (ind_matters(self.convbnrelu_1) or split == 0 or not trunk_sharing_enabled()
+                or not shared_trunk.possible(trunk)):
+            return self.forward(x, force_passport, 0), self.forward(x, force_passport, 1)   # hooks: the caller fires them
+        with shared_trunk(trunk):
+            out, skip = self._stem(x, force_passport, 0)
+            for li, bi, block in blocks[:split]:
+                if li >= 2 and bi == 0:
+                    out, skip = cuts.mark('layer%d.%d' % (li + 1, bi), out, skip)
+                out, skip = block.forward_pair(out, skip, force_passport, 0)
+        if split < len(blocks) and blocks[split][0] >= 2 and blocks[split][1] == 0:
+            # a cut right where the branches part: ONE pair of leaves for both branches (their gradients meet there in
+            # the order of the un-cut backward pass)
+            out, skip = cuts.mark('layer%d.%d' % (blocks[split][0] + 1, 0), out, skip)
+        outs = []
+        for ind in (0, 1):                               # public branch first: the reference's order of norm updates
+            with gamma_beta_batch(self.passport_layers() if x.is_cuda else (), force_passport, ind, stage_groups(self)):
+                outs.append(self._head(self._run_blocks(out, skip, blocks[split:], force_passport, ind, marked=True)))
+        return outs[0], outs[1]
 
 
 def ResNet18Passport(**model_kwargs):

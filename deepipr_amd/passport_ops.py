@@ -741,7 +741,8 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     if need_dw:
         dw = dw.contiguous()
         if defer is not None:
-            defer[0].wgrads[defer[1]] = dw
+            defer[0].wgrads[defer[1]] = dw               # completed and handed to autograd by the group node
+            dw = None
         else:
             dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw)
     return dx, dw
@@ -760,13 +761,15 @@ class _Rank2Group(torch.autograd.Function):
 
     Forward is bookkeeping only: the gamma / beta pairs the batched GEMV launch already produced (gamma_beta_batch) are
     handed out as outputs of this node, so that autograd knows they come from the layers' weights.  Each layer's fused
-    node takes its pair as gamma_in / beta_in, and in backward returns dgamma / dbeta (sign-loss gradient included)
-    for them instead of launching its own rank-2 update; it leaves MIOpen's wgrad buffer of its weight with the share.
-    This node's backward runs when ALL its layers have been through backward (autograd's dependency count) and adds
-    dgamma_i (x) m_scale_i + dbeta_i (x) m_bias_i INTO those buffers in one launch.  It returns no gradient of its
-    own: the weights' AccumulateGrad nodes wait for both of a weight's consumers (the layer node and this one) and
-    then see the layer node's buffer, complete.  ResNet18: 5 launches of 4-6 us -> one of ~11 us for 67 MB
-    (profiles/r03_gemv_bench.json).  A group never spans two backward stages of the staged step (gamma_beta_batch)."""
+    node takes its pair as gamma_in / beta_in; in backward it returns dgamma / dbeta (sign-loss gradient included)
+    for them instead of launching its own rank-2 update, returns NO weight gradient itself and leaves MIOpen's wgrad
+    buffer of its weight with the share.  This node's backward runs when ALL its layers have been through backward
+    (autograd's dependency count), adds dgamma_i (x) m_scale_i + dbeta_i (x) m_bias_i INTO those buffers in one launch
+    and returns them as the weights' gradients: autograd only ever sees a weight's complete three-way gradient, as
+    one tensor (a weight used by two forward passes -- schemes V2 / V3 -- gets one such tensor per pass, summed by
+    autograd as before).  ResNet18: 5 launches of 4-7 us -> one of 11 us (back to back) / 18 us (in the step) for
+    67 MB (profiles/r03_gemv_bench.json).  A group never spans two backward stages of the staged step
+    (gamma_beta_batch)."""
 
     @staticmethod
     def forward(ctx, share, ms, pairs, *weights):
@@ -776,7 +779,7 @@ class _Rank2Group(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        share, dgs, dbs, ms, dws = ctx.share, [], [], [], []
+        share, dgs, dbs, ms, dws, out = ctx.share, [], [], [], [], [None] * ctx.n
         for i in range(ctx.n):
             dg, db = grads[2 * i], grads[2 * i + 1]
             if dg is None and db is None:
@@ -788,10 +791,13 @@ class _Rank2Group(torch.autograd.Function):
             dbs.append(db.contiguous())
             ms.append(ctx.ms[i])
             dws.append(dw)
-        share.wgrads.clear()
+            out[i] = dw
+        if share.wgrads:
+            raise RuntimeError('deepipr_amd: rank-2 group: wgrad buffers left without dgamma / dbeta: %s'
+                               % sorted(share.wgrads))
         if dws:
             kernels.gamma_beta_bwd_multi(dgs, dbs, ms, dws, accumulate=True)
-        return (None, None, None) + (None,) * ctx.n
+        return (None, None, None) + tuple(out)
 
 
 class _PassportLayer(torch.autograd.Function):
@@ -953,8 +959,8 @@ class gamma_beta_batch:
     cached pooled keys, so they are computed up front; each layer picks its pair up (PassportLayerBase._gb_pre) and its
     autograd node treats it as its own GEMV's result.  Backward: the layers of one GROUP (`group_of(layer)`: the
     backward stage the layer belongs to, models' backward_stages(); one group without it) leave the rank-2 update of
-    the shared weights' gradients to one launch per group (_Rank2Group); a layer alone in its group, or whose
-    convolution runs outside the fused node, does its own as before.  Pairs nobody used are dropped on exit.
+    the shared weights' gradients -- and handing those gradients to autograd -- to one launch per group (_Rank2Group);
+    a layer alone in its group, or whose convolution runs outside the fused node, does its own as before.  Pairs nobody used are dropped on exit.
     DEEPIPR_NO_GEMV_BATCH=1 switches the batching off, DEEPIPR_NO_RANK2_BATCH=1 only the backward part."""
 
     def __init__(self, layers, force_passport=False, ind=0, group_of=None):
@@ -1241,7 +1247,10 @@ def add_relu_fork(a, b):
     if _add_relu_fusable(a, b):
         return _AddReLUFork.apply(a, b)
     out = torch.relu(a + b)
-    return out, out
+    # two distinct handles also here: each collects its own consumers' gradients and the two sums meet in ONE add,
+    # whatever the number of consumers (the shared trunk of a V2 / V3 dual forward gives each handle two) -- the same
+    # association as the fused kernels' dy + dy2 and as the staged backward's per-handle leaves
+    return out.view_as(out), out.view_as(out)
 
 
 ADD_RELU_MIN_ELEMENTS = 1 << 18

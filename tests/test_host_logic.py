@@ -565,3 +565,74 @@ def test_staged_backward_equals_one_backward_pass(private, cpu_kernels):
             assert torch.equal(u, v)
     for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(u, v), k
+
+
+@pytest.mark.parametrize('arch', ['resnet18', 'alexnet'])
+def test_shared_trunk_of_the_dual_forward_equals_two_full_passes(arch, cpu_kernels, monkeypatch):
+    """V2 / V3 step (trainer_private.py:159-171: model(x, ind=0) and model(x, ind=1) over the same batch): the layers in
+    front of the first private passport layer run ONCE for both branches (models/_builders.shared_trunk).  Against the
+    two full passes (DEEPIPR_NO_SHARED_TRUNK=1): identical logits, gradients equal up to the association of the two
+    branches' sum, and -- the one thing the reference does twice that has an effect -- the batch-norm running
+    statistics after two updates with the same batch statistic, num_batches_tracked advanced by two; the net's own
+    forward hooks still see two calls."""
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from oracle.cases import alexnet_config, resnet18_config
+    torch.set_num_threads(8)
+    if arch == 'resnet18':
+        from deepipr_amd.models.resnet_passport_private import ResNet18Private
+        kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                                  'key_type': 'random', 'sl_ratio': 0.1})
+        ctor = lambda: ResNet18Private(num_classes=10, passport_kwargs=kw)
+        shared_bn, branch_bn = 'layer3.1.convbn_2.bn', 'layer4.0.convbnrelu_1.bn'
+    else:
+        from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+        kw = construct_passport_kwargs_from_dict({'passport_config': alexnet_config(), 'norm_type': 'bn',
+                                                  'key_type': 'random', 'sl_ratio': 0.1})
+        ctor = lambda: AlexNetPassportPrivate(3, 10, kw)
+        shared_bn, branch_bn = 'features.2.bn', 'features.4.bn'
+
+    def make():
+        torch.manual_seed(5)
+        np.random.seed(5)
+        net = ctor()
+        net.train()
+        with torch.no_grad():
+            net(torch.randn(2, 3, 32, 32))
+        return net
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(6, 3, 32, 32, generator=g), torch.randint(0, 10, (6,), generator=g)
+    res = {}
+    for mode in ('shared', 'twice'):
+        if mode == 'twice':
+            monkeypatch.setenv('DEEPIPR_NO_SHARED_TRUNK', '1')
+        else:
+            monkeypatch.delenv('DEEPIPR_NO_SHARED_TRUNK', raising=False)
+        net = make()
+        seen = []
+        net.register_forward_hook(lambda _m, _i, o: seen.append(o.detach().clone()))
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        calls = {'n': 0}
+        stem_conv = net.convbnrelu_1.conv if arch == 'resnet18' else net.features[0].conv
+        stem_conv.register_forward_hook(lambda *_a: calls.__setitem__('n', calls['n'] + 1))
+        train_step_v23(DualBranch(net), opt, x, y)
+        res[mode] = dict(logits=seen, grads={k: p.grad.clone() for k, p in net.named_parameters()},
+                         state={k: v.clone() for k, v in net.state_dict().items()}, stem_calls=calls['n'])
+    a, b = res['shared'], res['twice']
+    assert (a['stem_calls'], b['stem_calls']) == (1, 2)                  # the trunk really ran once
+    assert len(a['logits']) == len(b['logits']) == 2                    # the net's forward hooks: two calls
+    for u, v in zip(a['logits'], b['logits']):
+        assert torch.equal(u, v)
+    for k in b['grads']:
+        scale = float(b['grads'][k].abs().max()) + 1e-12
+        # one backward pass over the trunk with the branches' summed gradient against the sum of two passes: fp32
+        # reassociation through up to 13 layers, a few 1e-6 of scale (the north star's bar is 1e-4)
+        assert float((a['grads'][k] - b['grads'][k]).abs().max()) <= 2e-5 * scale + 1e-9, k
+    for k, v in b['state'].items():
+        if k.endswith('num_batches_tracked'):
+            assert int(a['state'][k]) == int(v) == 3, k          # the key-drawing forward in make() + two passes
+        else:
+            assert torch.allclose(a['state'][k], v, rtol=1e-5, atol=1e-7), k
+    # and the statistics did move twice: one update would leave running_mean at 0.1 * batch mean, two at 0.19 *
+    for name in (shared_bn, branch_bn):
+        assert float(a['state'][name + '.running_mean'].abs().max()) > 0

@@ -369,7 +369,7 @@ def test_external_event_of_a_captured_graph_orders_a_side_stream(K):
 
 
 # ----------------------------------------------------------------------------- rank-2 update of a layer group in one launch
-@pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2', 'alexnet_v1'])
+@pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2', 'resnet18_v2_private_pass_first', 'alexnet_v1'])
 def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_kind, monkeypatch):
     """The passport branch's dW of a group of layers in ONE launch (_Rank2Group, the default) against one launch per
     layer (DEEPIPR_NO_RANK2_BATCH=1) and against no batching at all (DEEPIPR_NO_GEMV_BATCH=1): logits and every
@@ -378,7 +378,8 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
     from deepipr_amd import _lib
     from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
     from oracle.cases import alexnet_config, resnet18_config
-    private = net_kind.endswith('v2')
+    private = 'v2' in net_kind
+    rev = net_kind.endswith('first')     # the private pass's nodes are then the OLDER ones: the other backward order
     if net_kind.startswith('resnet18'):
         from deepipr_amd.models.resnet_passport import ResNet18Passport
         from deepipr_amd.models.resnet_passport_private import ResNet18Private
@@ -412,7 +413,7 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
         net.zero_grad(set_to_none=True)
         _lib.profile_enable(True)
         if private:
-            outs = [net(x, ind=0), net(x, ind=1)]
+            outs = [net(x, ind=1), net(x, ind=0)] if rev else [net(x, ind=0), net(x, ind=1)]
             loss = ce(outs[0], y) + ce(outs[1], y) + sum(m.sign_loss_private.loss for m in net.modules()
                                                          if hasattr(m, 'sign_loss_private'))
         else:
@@ -431,13 +432,73 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
         grouped, f0, b0 = step(())
         per_layer, f1, b1 = step(('DEEPIPR_NO_RANK2_BATCH',))
         unbatched, f2, b2 = step(('DEEPIPR_NO_GEMV_BATCH',))
-    n_layers = {'resnet18_v1': 5, 'resnet18_v2': 5, 'alexnet_v1': 3}[net_kind]
+    n_layers = 3 if net_kind == 'alexnet_v1' else 5
     fwd_passes = 1                                              # V2: only the private pass (ind = 1) uses the passports
     assert (f1, b1) == (fwd_passes, n_layers * fwd_passes), (f1, b1)
     assert (f2, b2) == (n_layers * fwd_passes, n_layers * fwd_passes), (f2, b2)
     # one launch per group: ResNet18's five layers are one stage; AlexNet: features 5, 6 together, features 4 alone
-    assert (f0, b0) == (fwd_passes, {'resnet18_v1': 1, 'resnet18_v2': 1, 'alexnet_v1': 2}[net_kind]), (f0, b0)
+    assert (f0, b0) == (fwd_passes, 2 if net_kind == 'alexnet_v1' else 1), (f0, b0)
     for name, other in (('per layer', per_layer), ('unbatched', unbatched)):
         assert set(other) == set(grouped)
         diff = {k: float((grouped[k] - other[k]).abs().max()) for k in grouped if not torch.equal(grouped[k], other[k])}
         assert not diff, '%s: %d tensors differ: %s' % (name, len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:4])
+
+
+# ----------------------------------------------------------------------------- shared trunk of the V2 / V3 dual forward
+@pytest.mark.parametrize('graph', [False, True])
+def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
+    """ResNet18 V2 (config P shard: batch 32, 100 classes): the layers in front of layer4 run once for both branches
+    (models/_builders.shared_trunk) against the two full passes (DEEPIPR_NO_SHARED_TRUNK=1), eagerly and replayed from
+    the whole-step hipGraph: three steps each; logits-derived scalars, every parameter and every buffer (running
+    statistics after TWO updates per step, num_batches_tracked) agree -- gradients differ only by the association of
+    the two branches' sum."""
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.flat_sgd import FlatSGD
+    from deepipr_amd.models.resnet_passport_private import ResNet18Private
+    from oracle.cases import resnet18_config
+    kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(32, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 100, (32,), generator=g).to(DEV)
+    res = {}
+    with pinned_miopen():
+        for mode in ('shared', 'twice'):
+            if mode == 'twice':
+                monkeypatch.setenv('DEEPIPR_NO_SHARED_TRUNK', '1')
+            else:
+                monkeypatch.delenv('DEEPIPR_NO_SHARED_TRUNK', raising=False)
+            torch.manual_seed(4)
+            np.random.seed(4)
+            net = ResNet18Private(num_classes=100, passport_kwargs=kw).to(DEV)
+            net.train()
+            with torch.no_grad():
+                net(x)
+            dual = DualBranch(net)
+            opt = FlatSGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+            calls = {'n': 0}
+            net.convbnrelu_1.conv.register_forward_hook(lambda *_a: calls.__setitem__('n', calls['n'] + 1))
+            if graph:
+                net.convbnrelu_1.conv._forward_hooks.clear()       # no Python side effects inside a capture
+                step = GraphedTrainStep(train_step_v23, dual, opt, x, y)
+                outs = [tuple(float(v) for v in step(x, y)) for _ in range(3)]
+            else:
+                outs = [tuple(float(v) for v in train_step_v23(dual, opt, x, y)) for _ in range(3)]
+            torch.cuda.synchronize()
+            res[mode] = dict(outs=outs, state={k: v.detach().clone() for k, v in net.state_dict().items()},
+                             calls=calls['n'])
+    a, b = res['shared'], res['twice']
+    if not graph:
+        assert (a['calls'], b['calls']) == (1 + 3, 1 + 6), (a['calls'], b['calls'])     # + the key-drawing forward
+    if not graph:
+        assert a['outs'][0] == b['outs'][0], (a['outs'][0], b['outs'][0])  # first step: identical forward, bit for bit
+    for u, v in zip(a['outs'], b['outs']):
+        assert np.allclose(u, v, rtol=1e-4, atol=1e-5), (u, v)
+    for k, v in b['state'].items():
+        if k.endswith('num_batches_tracked'):
+            assert int(a['state'][k]) == int(v), k
+        else:
+            scale = float(v.abs().max()) + 1e-12
+            assert float((a['state'][k] - v).abs().max()) <= 1e-4 * scale + 1e-7, k
