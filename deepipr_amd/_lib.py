@@ -73,6 +73,12 @@ SIGNATURES = {
     'deepipr_passport_bn_resident': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_bn_slices': (_int, [_int, _int, _int]),
     'deepipr_passport_bn_passes': (_int, [_int, _int, _int, _int]),
+    'deepipr_bn_dual_tail_supported': (_int, [_int, _int, _int, _int]),
+    'deepipr_bn_dual_tail_fwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _vp, _f32p, _f32p, _vp,
+                                        _flt, _flt, _flt, _flt, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _vp,
+                                        _vp]),
+    'deepipr_bn_dual_tail_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                        _f32p, _f32p, _int, _int, _int, _int, _int, _vp, _vp]),
     'deepipr_passport_gn_supported': (_int, [_int, _int, _int, _int]),
     'deepipr_passport_gn_workspace_bytes': (_sz, [_int, _int, _int]),
     'deepipr_passport_gn_fwd': (_int, [_f32p, _f32p, _f64p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _int, _flt, _int,
@@ -88,7 +94,7 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_debug_trace': (_int, [_vp]),
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 

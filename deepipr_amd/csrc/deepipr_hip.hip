@@ -1569,6 +1569,54 @@ __device__ __forceinline__ void res_block_sums(double &a, double &b, const ResPl
     }
 }
 
+// The same for four values at once (the dual kernels: two layers' sums): one barrier pair.  Two calls of the two-value
+// form in a row made the compiler keep the first call's 2 * T/64 LDS reads in flight across the second (+58 VGPRs on
+// the 1024-thread instances).  red: 4 * (T/64) * 8 doubles of LDS.  Per value the summation order is the two-value
+// form's (waves in index order), so the results are bit-identical to it.
+template <int T>
+__device__ __forceinline__ void res_block_sums4(double &a, double &b, double &c, double &d, const ResPlan &pl,
+                                                int c_local, double *red) {
+    constexpr int NW = T / kWave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (pl.G == 1) {
+        a = wave_sum(a);
+        b = wave_sum(b);
+        c = wave_sum(c);
+        d = wave_sum(d);
+    } else {
+        for (int off = kWave / 2; off >= pl.gq; off >>= 1) {
+            a += __shfl_xor(a, off, kWave);
+            b += __shfl_xor(b, off, kWave);
+            c += __shfl_xor(c, off, kWave);
+            d += __shfl_xor(d, off, kWave);
+        }
+        for (int off = pl.q4 >> 1; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, kWave);
+            b += __shfl_xor(b, off, kWave);
+            c += __shfl_xor(c, off, kWave);
+            d += __shfl_xor(d, off, kWave);
+        }
+    }
+    __syncthreads();
+    if (lane < pl.gq && lane == c_local * pl.q4) {
+        double *row = red + (wave * 8 + c_local) * 4;
+        row[0] = a;
+        row[1] = b;
+        row[2] = c;
+        row[3] = d;
+    }
+    __syncthreads();
+    a = b = c = d = 0.0;
+#pragma unroll 2
+    for (int w = 0; w < NW; ++w) {
+        const double *row = red + (w * 8 + c_local) * 4;
+        a += row[0];
+        b += row[1];
+        c += row[2];
+        d += row[3];
+    }
+}
+
 // In-launch exchange of one channel's two partial sums (doubles) between its S slice workgroups, run by WAVE 0.
 //
 // Transport: data-tagged granules (MI355X_MICROARCH.md, hand-off price list: "handoff-1to1", the cheapest valid
@@ -1984,9 +2032,10 @@ struct DualFwdArgs {
 template <int T, int F4>
 __global__ __launch_bounds__(T) void k_bn_dual_fwd(
     const float4 *__restrict__ xa, float4 *__restrict__ y, const float *__restrict__ gamma_a,
-    const float *__restrict__ beta_a, int N, int C, ResPlan pl, BnFinishArgs f, DualFwdArgs d, unsigned *sync) {
+    const float *__restrict__ beta_a, int relu_a, int relu_b, int N, int C, ResPlan pl, BnFinishArgs f,
+    DualFwdArgs d, unsigned *sync) {
     constexpr int NW = T / kWave;
-    __shared__ double red[2 * NW * 8];
+    __shared__ double red[4 * NW * 8];
     __shared__ double xch[4];
     const int t = threadIdx.x;
     int cb, s;
@@ -2047,8 +2096,7 @@ __global__ __launch_bounds__(T) void k_bn_dual_fwd(
     }
     double sa1 = static_cast<double>(a0), sa2 = static_cast<double>(a1);
     double sb1 = static_cast<double>(b0), sb2 = static_cast<double>(b1);
-    res_block_sums<T>(sa1, sa2, pl, c_local, red);
-    res_block_sums<T>(sb1, sb2, pl, c_local, red);
+    res_block_sums4<T>(sa1, sa2, sb1, sb2, pl, c_local, red);
     if (pl.S > 1) {                                   // G == 1 here
         if (t < kWave) {
             res_exchange(sa1, sa2, xca, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
@@ -2099,10 +2147,19 @@ __global__ __launch_bounds__(T) void k_bn_dual_fwd(
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
         if (j < units) {
-            const float4 o = make_float4(bn_affine1<false>(va[k].x, cha), bn_affine1<false>(va[k].y, cha),
-                                         bn_affine1<false>(va[k].z, cha), bn_affine1<false>(va[k].w, cha));
-            const float4 r = make_float4(bn_affine1<false>(vb[k].x, chb), bn_affine1<false>(vb[k].y, chb),
-                                         bn_affine1<false>(vb[k].z, chb), bn_affine1<false>(vb[k].w, chb));
+            float4 o, r;
+            if (relu_a)
+                o = make_float4(bn_affine1<true>(va[k].x, cha), bn_affine1<true>(va[k].y, cha),
+                                bn_affine1<true>(va[k].z, cha), bn_affine1<true>(va[k].w, cha));
+            else
+                o = make_float4(bn_affine1<false>(va[k].x, cha), bn_affine1<false>(va[k].y, cha),
+                                bn_affine1<false>(va[k].z, cha), bn_affine1<false>(va[k].w, cha));
+            if (relu_b)
+                r = make_float4(bn_affine1<true>(vb[k].x, chb), bn_affine1<true>(vb[k].y, chb),
+                                bn_affine1<true>(vb[k].z, chb), bn_affine1<true>(vb[k].w, chb));
+            else
+                r = make_float4(bn_affine1<false>(vb[k].x, chb), bn_affine1<false>(vb[k].y, chb),
+                                bn_affine1<false>(vb[k].z, chb), bn_affine1<false>(vb[k].w, chb));
             y[idx[k]] = make_float4(relu1(o.x + r.x), relu1(o.y + r.y), relu1(o.z + r.z), relu1(o.w + r.w));
         }
     }
@@ -2121,9 +2178,9 @@ struct DualBwdArgs {
 template <int T, int F4>
 __global__ __launch_bounds__(T) void k_bn_dual_bwd(
     const float4 *__restrict__ dy, const float4 *__restrict__ xa, const float *__restrict__ tbl_a,
-    float4 *__restrict__ dxa, int N, int C, ResPlan pl, unsigned *sync, DualBwdArgs a) {
+    float4 *__restrict__ dxa, int relu_a, int relu_b, int N, int C, ResPlan pl, unsigned *sync, DualBwdArgs a) {
     constexpr int NW = T / kWave;
-    __shared__ double red[2 * NW * 8];
+    __shared__ double red[4 * NW * 8];
     __shared__ double xch[4];
     const int t = threadIdx.x;
     int cb, s;
@@ -2163,27 +2220,35 @@ __global__ __launch_bounds__(T) void k_bn_dual_bwd(
                                 o.w > 0.0f ? g.w : 0.0f);
         }
     }
-    float a0 = 0.0f, b0 = 0.0f, a1 = 0.0f;
+    // dz_a = d masked by layer a's own ReLU (recomputed from xhat, as in k_bn_res_bwd), dz_b likewise: only d and the
+    // two xhat stay in registers, the masks are formed again in the write phase (same expression, same bits)
+    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
-        ha[k] = make_float4((ha[k].x - cha.x) * cha.y, (ha[k].y - cha.x) * cha.y, (ha[k].z - cha.x) * cha.y,
-                            (ha[k].w - cha.x) * cha.y);
-        hb[k] = make_float4((hb[k].x - chb.x) * chb.y, (hb[k].y - chb.x) * chb.y, (hb[k].z - chb.x) * chb.y,
-                            (hb[k].w - chb.x) * chb.y);
-        a0 = fmaf(dz[k].x, ha[k].x, a0);
-        a0 = fmaf(dz[k].y, ha[k].y, a0);
-        a0 = fmaf(dz[k].z, ha[k].z, a0);
-        a0 = fmaf(dz[k].w, ha[k].w, a0);
-        b0 = fmaf(dz[k].x, hb[k].x, b0);
-        b0 = fmaf(dz[k].y, hb[k].y, b0);
-        b0 = fmaf(dz[k].z, hb[k].z, b0);
-        b0 = fmaf(dz[k].w, hb[k].w, b0);
-        a1 += (dz[k].x + dz[k].y) + (dz[k].z + dz[k].w);
+        const float4 g = dz[k], va = ha[k], vb = hb[k];
+        float4 za, zb;
+        res_bwd_prep(g.x, va.x, cha, relu_a, za.x, ha[k].x);
+        res_bwd_prep(g.y, va.y, cha, relu_a, za.y, ha[k].y);
+        res_bwd_prep(g.z, va.z, cha, relu_a, za.z, ha[k].z);
+        res_bwd_prep(g.w, va.w, cha, relu_a, za.w, ha[k].w);
+        res_bwd_prep(g.x, vb.x, chb, relu_b, zb.x, hb[k].x);
+        res_bwd_prep(g.y, vb.y, chb, relu_b, zb.y, hb[k].y);
+        res_bwd_prep(g.z, vb.z, chb, relu_b, zb.z, hb[k].z);
+        res_bwd_prep(g.w, vb.w, chb, relu_b, zb.w, hb[k].w);
+        a0 = fmaf(za.x, ha[k].x, a0);
+        a0 = fmaf(za.y, ha[k].y, a0);
+        a0 = fmaf(za.z, ha[k].z, a0);
+        a0 = fmaf(za.w, ha[k].w, a0);
+        a1 += (za.x + za.y) + (za.z + za.w);
+        b0 = fmaf(zb.x, hb[k].x, b0);
+        b0 = fmaf(zb.y, hb[k].y, b0);
+        b0 = fmaf(zb.z, hb[k].z, b0);
+        b0 = fmaf(zb.w, hb[k].w, b0);
+        b1 += (zb.x + zb.y) + (zb.z + zb.w);
     }
     double aga = static_cast<double>(a0), ab = static_cast<double>(a1);
-    double agb = static_cast<double>(b0), ab2 = ab;
-    res_block_sums<T>(aga, ab, pl, c_local, red);
-    res_block_sums<T>(agb, ab2, pl, c_local, red);
+    double agb = static_cast<double>(b0), ab2 = static_cast<double>(b1);
+    res_block_sums4<T>(aga, ab, agb, ab2, pl, c_local, red);
     if (pl.S > 1) {
         if (t < kWave) {
             res_exchange(aga, ab, xca, s, pl.S, sync, DEEPIPR_RES_SPIN(pl), DEEPIPR_RES_DROP(pl));
@@ -2215,10 +2280,18 @@ __global__ __launch_bounds__(T) void k_bn_dual_bwd(
     for (int k = 0; k < F4; ++k) {
         const int j = t + k * T;
         if (j < units) {
-            dxa[idx[k]] = make_float4(sca * (dz[k].x - c2a - ha[k].x * c3a), sca * (dz[k].y - c2a - ha[k].y * c3a),
-                                      sca * (dz[k].z - c2a - ha[k].z * c3a), sca * (dz[k].w - c2a - ha[k].w * c3a));
-            a.dxb[idx[k]] = make_float4(scb * (dz[k].x - c2b - hb[k].x * c3b), scb * (dz[k].y - c2b - hb[k].y * c3b),
-                                        scb * (dz[k].z - c2b - hb[k].z * c3b), scb * (dz[k].w - c2b - hb[k].w * c3b));
+            const float4 g = dz[k];
+            auto masked = [](float dv, float xh, const float4 &ch, int relu) {
+                return (relu && !(__fadd_rn(__fmul_rn(ch.z, xh), ch.w) > 0.0f)) ? 0.0f : dv;
+            };
+            const float4 za = make_float4(masked(g.x, ha[k].x, cha, relu_a), masked(g.y, ha[k].y, cha, relu_a),
+                                          masked(g.z, ha[k].z, cha, relu_a), masked(g.w, ha[k].w, cha, relu_a));
+            const float4 zb = make_float4(masked(g.x, hb[k].x, chb, relu_b), masked(g.y, hb[k].y, chb, relu_b),
+                                          masked(g.z, hb[k].z, chb, relu_b), masked(g.w, hb[k].w, chb, relu_b));
+            dxa[idx[k]] = make_float4(sca * (za.x - c2a - ha[k].x * c3a), sca * (za.y - c2a - ha[k].y * c3a),
+                                      sca * (za.z - c2a - ha[k].z * c3a), sca * (za.w - c2a - ha[k].w * c3a));
+            a.dxb[idx[k]] = make_float4(scb * (zb.x - c2b - hb[k].x * c3b), scb * (zb.y - c2b - hb[k].y * c3b),
+                                        scb * (zb.z - c2b - hb[k].z * c3b), scb * (zb.w - c2b - hb[k].w * c3b));
         }
     }
 }
@@ -3373,6 +3446,109 @@ int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync) {
     if (plan_resident(N, C, HW, 16, have_sync != 0, &rp)) mask |= 1;
     if (plan_resident(N, C, HW, 8, have_sync != 0, &rp)) mask |= 2;
     return mask;
+}
+
+// ---- a projection block's last two norm layers + tail in one launch per direction (k_bn_dual_fwd / _bwd) ----
+namespace {
+#define DEEPIPR_DUAL_CASES_4(KERNEL, TT, ...)                                                                     \
+    switch (pl.F4) {                                                                                              \
+        case 1: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 1>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 2: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 2>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        case 3: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 3>), grid, dim3(TT), st, __VA_ARGS__); break;                    \
+        default: DEEPIPR_LAUNCH(prof, (KERNEL<TT, 4>), grid, dim3(TT), st, __VA_ARGS__); break;                   \
+    }
+
+// The plan both directions of the dual form share -- and the one the separate single-pass launches of the two layers
+// would take (same T, S, F4: that is what makes the dual form bit-identical to them).  Backward keeps three register
+// arrays per unit, so a 1024-thread workgroup is limited to 4 float4 per thread (a 256-thread one may use 8: one
+// wave per SIMD has the whole register file).
+bool plan_dual(int N, int C, int HW, bool can_sync, ResPlan *out) {
+    ResPlan rp;
+    if (!plan_resident(N, C, HW, 8, can_sync, &rp) || rp.passes != 1) return false;
+    if (rp.T == 1024 && rp.F4 > 4) return false;
+    if (rp.S > 1 && 2 * C > kXchChannels) return false;     // the second layer's exchange slots: cb + C
+    *out = rp;
+    return true;
+}
+}  // namespace
+
+int deepipr_bn_dual_tail_supported(int N, int C, int HW, int have_sync) {
+    if (bad_dims(N, C, HW)) return 0;
+    ResPlan rp;
+    return plan_dual(N, C, HW, have_sync != 0, &rp) ? 1 : 0;
+}
+
+int deepipr_bn_dual_tail_fwd(const float *xa, const float *xb, const float *gamma_a, const float *beta_a,
+                             const float *gamma_b, const float *beta_b, float *running_mean_a, float *running_var_a,
+                             long long *num_batches_tracked_a, float *running_mean_b, float *running_var_b,
+                             long long *num_batches_tracked_b, float momentum_a, float momentum_b, float eps_a,
+                             float eps_b, int relu_a, int relu_b, int N, int C, int HW, float *out, float *table_a,
+                             float *table_b, unsigned int *sync, void *stream) {
+    if (!xa || !xb || !gamma_a || !beta_a || !gamma_b || !beta_b || !out || !table_a || !table_b || bad_dims(N, C, HW))
+        return fail(DEEPIPR_EINVAL, "bn_dual_tail_fwd: bad argument");
+    if ((running_mean_a == nullptr) != (running_var_a == nullptr) || (running_mean_b == nullptr) != (running_var_b == nullptr))
+        return fail(DEEPIPR_EINVAL, "bn_dual_tail_fwd: running_mean and running_var go together");
+    if (!aligned16(xa) || !aligned16(xb) || !aligned16(out))
+        return fail(DEEPIPR_EINVAL, "bn_dual_tail_fwd: tensors must be 16-byte aligned");
+    ResPlan pl;
+    if (!plan_dual(N, C, HW, sync != nullptr, &pl))
+        return fail(DEEPIPR_EUNSUPPORTED, "bn_dual_tail_fwd: shape outside the dual form (ask deepipr_bn_dual_tail_supported)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BnFinishArgs f{};
+    const double M = static_cast<double>(N) * HW;
+    f.inv_m = 1.0 / M;
+    f.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
+    f.eps = eps_a;
+    f.momentum = momentum_a;
+    f.running_mean = running_mean_a;
+    f.running_var = running_var_a;
+    f.num_batches_tracked = num_batches_tracked_a;
+    f.tbl = table_a;
+    f.shift_src = xa;
+    f.HW = HW;
+    DualFwdArgs d{reinterpret_cast<const float4 *>(xb), gamma_b, beta_b, momentum_b, eps_b, running_mean_b,
+                  running_var_b, num_batches_tracked_b, table_b};
+    ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
+    prof.bytes = 12.0 * static_cast<double>(N) * C * HW;
+    const dim3 grid(pl.blocks);
+    const float4 *x4 = reinterpret_cast<const float4 *>(xa);
+    float4 *y4 = reinterpret_cast<float4 *>(out);
+    if (pl.T == 256) {
+        DEEPIPR_RES_CASES(k_bn_dual_fwd, 256, x4, y4, gamma_a, beta_a, relu_a, relu_b, N, C, pl, f, d, sync)
+    } else {
+        DEEPIPR_DUAL_CASES_4(k_bn_dual_fwd, 1024, x4, y4, gamma_a, beta_a, relu_a, relu_b, N, C, pl, f, d, sync)
+    }
+    return check_launch("bn_dual_tail_fwd");
+}
+
+int deepipr_bn_dual_tail_bwd(const float *dy, const float *dy2, const float *out, const float *xa, const float *xb,
+                             const float *table_a, const float *table_b, float *dxa, float *dxb, float *dgamma_a,
+                             float *dbeta_a, float *dgamma_b, float *dbeta_b, int relu_a, int relu_b, int N, int C,
+                             int HW, unsigned int *sync, void *stream) {
+    if (!dy || !out || !xa || !xb || !table_a || !table_b || !dxa || !dxb || !dgamma_a || !dbeta_a || !dgamma_b ||
+        !dbeta_b || bad_dims(N, C, HW))
+        return fail(DEEPIPR_EINVAL, "bn_dual_tail_bwd: bad argument");
+    if (!aligned16(dy) || !aligned16(out) || !aligned16(xa) || !aligned16(xb) || !aligned16(dxa) || !aligned16(dxb) ||
+        (dy2 && !aligned16(dy2)))
+        return fail(DEEPIPR_EINVAL, "bn_dual_tail_bwd: tensors must be 16-byte aligned");
+    ResPlan pl;
+    if (!plan_dual(N, C, HW, sync != nullptr, &pl))
+        return fail(DEEPIPR_EUNSUPPORTED, "bn_dual_tail_bwd: shape outside the dual form (ask deepipr_bn_dual_tail_supported)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DualBwdArgs a{reinterpret_cast<const float4 *>(dy2), reinterpret_cast<const float4 *>(out),
+                  reinterpret_cast<const float4 *>(xb), table_b, reinterpret_cast<float4 *>(dxb), dgamma_a, dbeta_a,
+                  dgamma_b, dbeta_b, 1.0 / (static_cast<double>(N) * HW)};
+    ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
+    prof.bytes = (dy2 ? 28.0 : 24.0) * static_cast<double>(N) * C * HW;
+    const dim3 grid(pl.blocks);
+    const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(xa);
+    float4 *o4 = reinterpret_cast<float4 *>(dxa);
+    if (pl.T == 256) {
+        DEEPIPR_RES_CASES(k_bn_dual_bwd, 256, d4, x4, table_a, o4, relu_a, relu_b, N, C, pl, sync, a)
+    } else {
+        DEEPIPR_DUAL_CASES_4(k_bn_dual_bwd, 1024, d4, x4, table_a, o4, relu_a, relu_b, N, C, pl, sync, a)
+    }
+    return check_launch("bn_dual_tail_bwd");
 }
 
 int deepipr_passport_bn_passes(int N, int C, int HW, int backward) {

@@ -72,3 +72,27 @@ class ConvBlock(nn.Module):
         if self.relu is not None:
             x = self.relu(x)
         return x
+
+
+def _hooked(*modules):
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in modules)
+
+
+def dual_tail(main, short, x, skip):
+    """relu(main(x) + short(skip)) for the last layer and the projection shortcut of a residual block when both are
+    plain ConvBlocks (models/resnet_passport.py:67-85): the two convolutions, then ONE fused launch per direction for
+    both norm layers and the tail (passport_ops.bn_dual_tail).  -> the pair of output handles, or None when the
+    pair does not qualify (the caller then runs the two layers one after the other)."""
+    if not (isinstance(main, ConvBlock) and isinstance(short, ConvBlock) and x.is_cuda and x.dtype == torch.float32
+            and main.fuse_norm and short.fuse_norm):
+        return None
+    if _hooked(main, short, main.conv, short.conv, main.bn, short.bn):
+        return None                                   # module hooks want to see each layer
+    from deepipr_amd import passport_ops as P
+    shape = P.conv_out_shape(x, main.conv)
+    if shape != P.conv_out_shape(skip, short.conv) or shape[0] * shape[1] * shape[2] * shape[3] < FUSE_MIN_ELEMENTS:
+        return None
+    if not P.bn_dual_tail_usable(main.bn, short.bn, shape):
+        return None
+    return P.bn_dual_tail(main.conv(x), short.conv(skip), main.bn, short.bn, main.relu is not None,
+                          short.relu is not None)

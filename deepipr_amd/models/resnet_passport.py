@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from deepipr_amd import cuts
 from deepipr_amd.models._builders import ind_matters, shared_trunk, trunk_sharing_enabled, PASSPORT_TYPES, conv_factory, run_layer, run_layer_tail
+from deepipr_amd.models.layers.conv2d import dual_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.passport_ops import gamma_beta_batch, stage_groups
 
@@ -63,6 +64,10 @@ class BasicPassportBlock(nn.Module):
         out = run_layer(self.convbnrelu_1, x, force_passport, ind)
         if isinstance(self.convbn_2, PASSPORT_TYPES):
             self.convbn_2.ensure_key(out)                # lazily drawn random keys: the reference's layer order
+        if self.has_projection():
+            pair = dual_tail(self.convbn_2, self.shortcut, out, skip)     # both plain ConvBlocks: one launch for the two
+            if pair is not None:                                          # norm layers and the tail
+                return pair
         sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
         # convbn_2, + shortcut, ReLU: folded into convbn_2's own norm kernels when they take the single-pass form
         return run_layer_tail(self.convbn_2, out, sc, force_passport, ind)
@@ -240,6 +245,10 @@ class BottleneckPassportBlock(nn.Module):
         out = run_layer(self.convbnrelu_2, out, force_passport, ind)
         if isinstance(self.convbn_3, PASSPORT_TYPES):
             self.convbn_3.ensure_key(out)
+        if self.has_projection():
+            pair = dual_tail(self.convbn_2, self.shortcut, out, skip)     # both plain ConvBlocks: one launch for the two
+            if pair is not None:                                          # norm layers and the tail
+                return pair
         sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
         return run_layer_tail(self.convbn_3, out, sc, force_passport, ind)
 

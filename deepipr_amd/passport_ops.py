@@ -393,6 +393,55 @@ class HipKernels:
             v = self._resident[key] = _lib.lib().deepipr_passport_bn_resident(n, c, hw, int(self.allow_sync))
         return v
 
+    def bn_dual_supported(self, n, c, hw):
+        """Both directions of this shape can take the dual form (deepipr_bn_dual_tail_*: a projection block's last two
+        norm layers + tail in one launch)."""
+        key = ('dual', n, c, hw, self.allow_sync)
+        v = self._resident.get(key)
+        if v is None:
+            v = self._resident[key] = bool(_lib.lib().deepipr_bn_dual_tail_supported(n, c, hw, int(self.allow_sync)))
+        return v
+
+    def bn_dual_tail_fwd(self, xa, xb, ga, ba, gb, bb, stats_a, stats_b, relu_a=True, relu_b=True):
+        """out = relu(act_a(bn_a(xa)) + act_b(bn_b(xb))) with learnable per-channel weight / bias, batch statistics;
+        stats_* = (running_mean, running_var, num_batches_tracked, momentum, eps).  -> out, table_a, table_b."""
+        dev = _chk(xa, xb)
+        n, c = xa.shape[0], xa.shape[1]
+        hw = xa.numel() // (n * c)
+        st = _stream(dev)
+        out = torch.empty_like(xa)
+        tables = torch.empty((2, c, 8), dtype=torch.float32, device=dev)
+        sync = self._sync_words(dev, st)
+        if sync is not None and self.bn_slices(n, c, hw) > 1:
+            self.sync_launches += 1
+        (rma, rva, nbta, moma, epsa), (rmb, rvb, nbtb, momb, epsb) = stats_a, stats_b
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_bn_dual_tail_fwd(
+                xa.data_ptr(), xb.data_ptr(), _p(ga), _p(ba), _p(gb), _p(bb), _p(rma), _p(rva), _p(nbta), _p(rmb),
+                _p(rvb), _p(nbtb), float(moma), float(momb), float(epsa), float(epsb), int(relu_a), int(relu_b), n, c, hw,
+                out.data_ptr(),
+                tables[0].data_ptr(), tables[1].data_ptr(), sync, st), 'bn_dual_tail_fwd')
+        return out, tables[0], tables[1]
+
+    def bn_dual_tail_bwd(self, dy, dy2, out, xa, xb, table_a, table_b, relu_a=True, relu_b=True):
+        """-> dxa, dxb, dgamma_a, dbeta_a, dgamma_b, dbeta_b."""
+        dev = _chk(dy, dy2, out, xa, xb)
+        n, c = xa.shape[0], xa.shape[1]
+        hw = xa.numel() // (n * c)
+        st = _stream(dev)
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        d = torch.empty((4, c), dtype=torch.float32, device=dev)
+        pd = d.data_ptr()
+        sync = self._sync_words(dev, st)
+        if sync is not None and self.bn_slices(n, c, hw) > 1:
+            self.sync_launches += 1
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_bn_dual_tail_bwd(
+                dy.data_ptr(), _p(dy2), out.data_ptr(), xa.data_ptr(), xb.data_ptr(), table_a.data_ptr(),
+                table_b.data_ptr(), dxa.data_ptr(), dxb.data_ptr(), pd, pd + 4 * c, pd + 8 * c, pd + 12 * c, int(relu_a),
+                int(relu_b), n, c, hw, sync, st), 'bn_dual_tail_bwd')
+        return dxa, dxb, d[0], d[1], d[2], d[3]
+
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
                         momentum, eps, training, margin=MARGIN, l2=L2, residual=None, pre=False):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x; with `residual`
@@ -928,6 +977,66 @@ class _PassportBNLayer(torch.autograd.Function):
         own = w is None or deferred                       # dgamma / dbeta travel on to whoever produced gamma_in / beta_in
         return (dx, dw, dsk if ctx.needs_input_grad[2] else None, dk if ctx.needs_input_grad[3] else None,
                 dg if own else None, db if own else None, None, None, None, None, None, dres, None)
+
+
+class _BNDualTail(torch.autograd.Function):
+    """out = relu(act_a(bn_a(xa)) + act_b(bn_b(xb))): a projection block's convbn_2 and shortcut norm layers
+    (BatchNorm2d with learnable weight / bias, each with or without its own ReLU -- the reference builds both with one,
+    models/resnet_passport.py:26-30) and the block's tail in ONE launch per direction
+    (deepipr_bn_dual_tail_fwd / _bwd; models/resnet_passport.py:67-85).  The output comes out twice, like every
+    block output (two consumers, whose gradients the backward kernel sums).  Bit-identical to the two separate fused
+    layer calls; if the dual form is not available at backward time (the exchange words were withheld meanwhile) the
+    separate backward kernels run on the same saved tensors."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, ga, ba, gb, bb, stats_a, stats_b, relus):
+        xa, xb = xa.contiguous(), xb.contiguous()
+        out, ta, tb = kernels.bn_dual_tail_fwd(xa, xb, ga.contiguous(), ba.contiguous(), gb.contiguous(),
+                                               bb.contiguous(), stats_a, stats_b, *relus)
+        ctx.relus = relus
+        ctx.save_for_backward(xa, xb, ta, tb, out)
+        ctx.set_materialize_grads(False)
+        return out, out.detach().view_as(out)
+
+    @staticmethod
+    def backward(ctx, dy, dy2):
+        xa, xb, ta, tb, out = ctx.saved_tensors
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            dy = torch.zeros_like(out)
+        dy = dy.contiguous()
+        dy2 = None if dy2 is None else dy2.contiguous()
+        n, c = xa.shape[0], xa.shape[1]
+        if kernels.bn_dual_supported(n, c, xa.numel() // (n * c)):
+            dxa, dxb, dga, dba, dgb, dbb = kernels.bn_dual_tail_bwd(dy, dy2, out, xa, xb, ta, tb, *ctx.relus)
+        else:
+            dxa, _dw, dga, dba, dres = kernels.passport_bn_bwd(dy, xa, ta, None, None, 0.0, None, None, None, None,
+                                                               ctx.relus[0], True, dy2=dy2, tail_out=out)
+            dxb, _dw, dgb, dbb = kernels.passport_bn_bwd(dres, xb, tb, None, None, 0.0, None, None, None, None,
+                                                         ctx.relus[1], True)
+        return dxa, dxb, dga, dba, dgb, dbb, None, None, None
+
+
+def bn_dual_tail_usable(bn_a, bn_b, shape):
+    """Both norms are BatchNorm2d(affine) on batch statistics with the default running average and the shape
+    [N, C, H, W] takes the dual form in both directions.  DEEPIPR_NO_DUAL_TAIL=1 (or DEEPIPR_TAIL_FUSION=0) keeps the
+    two separate fused layer calls."""
+    if os.environ.get('DEEPIPR_NO_DUAL_TAIL') == '1' or os.environ.get('DEEPIPR_TAIL_FUSION', '1') == '0':
+        return False
+    for bn in (bn_a, bn_b):
+        if not (isinstance(bn, torch.nn.BatchNorm2d) and bn.affine and bn.momentum is not None and bn.training
+                and bn.track_running_stats):
+            return False
+    n, c, h, w = shape
+    return kernels.bn_dual_supported(n, c, h * w)
+
+
+def bn_dual_tail(xa, xb, bn_a, bn_b, relu_a=True, relu_b=True):
+    """-> the pair of handles of relu(act_a(bn_a(xa)) + act_b(bn_b(xb))) (see _BNDualTail)."""
+    stats = [(bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps) for bn in (bn_a, bn_b)]
+    return _BNDualTail.apply(xa, xb, bn_a.weight, bn_a.bias, bn_b.weight, bn_b.bias, stats[0], stats[1],
+                             (bool(relu_a), bool(relu_b)))
 
 
 def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual, conv=None,

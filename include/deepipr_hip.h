@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 5
+#define DEEPIPR_ABI_VERSION 6
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -278,6 +278,29 @@ int deepipr_passport_bn_slices(int N, int C, int HW);
  * many channels as fill the chip once every channel is split over up to 64 workgroups; still 8 / 12 B per element);
  * 0 = not single-pass (three launches). */
 int deepipr_passport_bn_passes(int N, int C, int HW, int backward);
+/* A projection block's LAST TWO norm layers and its tail in one launch per direction
+ * (models/resnet_passport.py:67-85: out = relu(block_2(h) + block_s(x)), both ConvBlocks = conv -> BatchNorm2d(affine)
+ * -> ReLU, models/layers/conv2d.py:5-36; relu_a / relu_b say whether the inner ReLUs exist -- the reference builds
+ * both with one).  xa = conv_2's output, xb = the shortcut conv's, same
+ * shape [N, C, HW]; gamma_* / beta_* the norms' learnable weight / bias; batch statistics (training), running
+ * statistics updated as in deepipr_passport_bn_fwd; table_a / table_b [C][8] receive {mean, invstd, gamma, beta}
+ * for backward.  forward reads xa, xb and writes `out` (12 B/element; the two layers' own outputs are never
+ * written); backward forms d = (dy + dy2) * [out > 0] in registers (dy2 may be NULL), masks it with each layer's own
+ * ReLU and writes dxa, dxb, dgamma_* and dbeta_* (28 B/element against 36 of the two separate launches).  Bit-identical to deepipr_passport_bn_fwd /_bwd
+ * called for the shortcut layer and then, with residual / tail_out, for the other.  Single-pass shapes only:
+ * deepipr_bn_dual_tail_supported(N, C, HW, have_sync) -> 1, otherwise the entry points return DEEPIPR_EUNSUPPORTED
+ * and enqueue nothing.  `sync` as for deepipr_passport_bn_fwd. */
+int deepipr_bn_dual_tail_supported(int N, int C, int HW, int have_sync);
+int deepipr_bn_dual_tail_fwd(const float *xa, const float *xb, const float *gamma_a, const float *beta_a,
+                             const float *gamma_b, const float *beta_b, float *running_mean_a, float *running_var_a,
+                             long long *num_batches_tracked_a, float *running_mean_b, float *running_var_b,
+                             long long *num_batches_tracked_b, float momentum_a, float momentum_b, float eps_a,
+                             float eps_b, int relu_a, int relu_b, int N, int C, int HW, float *out, float *table_a,
+                             float *table_b, unsigned int *sync, void *stream);
+int deepipr_bn_dual_tail_bwd(const float *dy, const float *dy2, const float *out, const float *xa, const float *xb,
+                             const float *table_a, const float *table_b, float *dxa, float *dxb, float *dgamma_a,
+                             float *dbeta_a, float *dgamma_b, float *dbeta_b, int relu_a, int relu_b, int N, int C,
+                             int HW, unsigned int *sync, void *stream);
 size_t deepipr_passport_bn_workspace_bytes(int N, int C, int HW);
 int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, const float *gamma_in,
                             const float *beta_in, const float *b, float alpha, float margin, float l2,

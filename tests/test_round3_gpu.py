@@ -491,7 +491,7 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
                              calls=calls['n'])
     a, b = res['shared'], res['twice']
     if not graph:
-        assert (a['calls'], b['calls']) == (1 + 3, 1 + 6), (a['calls'], b['calls'])     # + the key-drawing forward
+        assert (a['calls'], b['calls']) == (3, 6), (a['calls'], b['calls'])     # the trunk really runs once per step
     if not graph:
         assert a['outs'][0] == b['outs'][0], (a['outs'][0], b['outs'][0])  # first step: identical forward, bit for bit
     for u, v in zip(a['outs'], b['outs']):
@@ -502,3 +502,119 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
         else:
             scale = float(v.abs().max()) + 1e-12
             assert float((a['state'][k] - v).abs().max()) <= 1e-4 * scale + 1e-7, k
+
+
+# ----------------------------------------------------------------------------- dual form: two norm layers + tail, one launch
+DUAL_SHAPES = [(128, 128, 16, 16), (128, 256, 8, 8), (128, 512, 4, 4), (32, 128, 16, 16), (64, 64, 16, 16),
+               (50, 128, 16, 16), (32, 256, 8, 8)]
+
+
+@pytest.mark.parametrize('relus', [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize('shape', DUAL_SHAPES)
+def test_dual_tail_kernels_equal_the_two_separate_fused_layers(K, shape, relus):
+    """deepipr_bn_dual_tail_fwd / _bwd (a projection block's last two norm layers + tail, one launch per direction)
+    against deepipr_passport_bn_fwd / _bwd called for the shortcut layer and then, with residual / tail_out, for the
+    other: out, channel tables, running statistics, dxa, dxb, dgamma, dbeta -- bit for bit; and against float64."""
+    n, c, h, w = shape
+    if not K.bn_dual_supported(n, c, h * w):
+        pytest.skip('shape outside the dual form')
+    g = torch.Generator().manual_seed(n + c)
+    xa = (torch.randn(n, c, h, w, generator=g) * 1.3 + 0.2).to(DEV)
+    xb = (torch.randn(n, c, h, w, generator=g) * 0.7 - 0.1).to(DEV)
+    ga, ba, gb, bb = [(torch.randn(c, generator=g) * s + o).to(DEV) for s, o in ((0.5, 1.0), (0.3, 0.0), (0.5, 1.0), (0.3, 0.1))]
+    dy = torch.randn(n, c, h, w, generator=g).to(DEV)
+    dy2 = torch.randn(n, c, h, w, generator=g).to(DEV)
+
+    def stats():
+        return [torch.zeros(c, device=DEV), torch.ones(c, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)]
+    ra, rb = stats(), stats()
+    out, ta, tb = K.bn_dual_tail_fwd(xa, xb, ga, ba, gb, bb, (*ra, 0.1, 1e-5), (*rb, 0.1, 1e-5), *relus)
+    dxa, dxb, dga, dba, dgb, dbb = K.bn_dual_tail_bwd(dy, dy2, out, xa, xb, ta, tb, *relus)
+    # the separate path: shortcut layer (b) first, then layer a with the tail folded in
+    sa, sb = stats(), stats()
+    yb, tb2 = K.passport_bn_fwd(xb, None, None, gb, bb, None, 0.0, relus[1], *sb, 0.1, 1e-5, True)[:2]
+    out2, ta2 = K.passport_bn_fwd(xa, None, None, ga, ba, None, 0.0, relus[0], *sa, 0.1, 1e-5, True, residual=yb)[:2]
+    dxa2, _dw, dga2, dba2, dres = K.passport_bn_bwd(dy, xa, ta2, None, None, 0.0, None, None, None, None, relus[0], True,
+                                                    dy2=dy2, tail_out=out2)
+    dxb2, _dw, dgb2, dbb2 = K.passport_bn_bwd(dres, xb, tb2, None, None, 0.0, None, None, None, None, relus[1], True)
+    torch.cuda.synchronize()
+    for name, u, v in (('out', out, out2), ('table_a', ta[:, :4], ta2[:, :4]), ('table_b', tb[:, :4], tb2[:, :4]),
+                       ('rm_a', ra[0], sa[0]), ('rv_a', ra[1], sa[1]), ('rm_b', rb[0], sb[0]), ('rv_b', rb[1], sb[1]),
+                       ('nbt_a', ra[2], sa[2]), ('nbt_b', rb[2], sb[2]),
+                       ('dxa', dxa, dxa2), ('dxb', dxb, dxb2), ('dga', dga, dga2), ('dba', dba, dba2),
+                       ('dgb', dgb, dgb2), ('dbb', dbb, dbb2)):
+        assert torch.equal(u, v), (name, float((u.double() - v.double()).abs().max()))
+    # float64 reference of the whole expression
+    A, B = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+    P = [t.double().requires_grad_(True) for t in (ga, ba, gb, bb)]
+
+    def layer(x, gm, bt, relu):
+        mu = x.mean((0, 2, 3), keepdim=True)
+        var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+        y = (x - mu) / torch.sqrt(var + 1e-5) * gm.view(1, -1, 1, 1) + bt.view(1, -1, 1, 1)
+        return torch.relu(y) if relu else y
+    ref = torch.relu(layer(A, P[0], P[1], relus[0]) + layer(B, P[2], P[3], relus[1]))
+    ref.backward((dy + dy2).double())
+    assert float((out.double() - ref).abs().max()) < 1e-4
+    for name, got, want in (('dxa', dxa, A.grad), ('dxb', dxb, B.grad), ('dga', dga, P[0].grad), ('dba', dba, P[1].grad),
+                            ('dgb', dgb, P[2].grad), ('dbb', dbb, P[3].grad)):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got.double() - want).abs().max()) <= 2e-4 * scale, (name, scale)
+
+
+@pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2'])
+def test_dual_tail_is_bit_identical_at_model_level(K, net_kind, monkeypatch):
+    """ResNet18: layer2.0 and layer3.0 (plain ConvBlocks: convbn_2 + projection shortcut) take the dual form by
+    default; DEEPIPR_NO_DUAL_TAIL=1 runs the two layers one after the other.  Logits and every parameter gradient
+    bit-identical with MIOpen pinned, two fused launches less per direction."""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.resnet_passport import ResNet18Passport
+    from deepipr_amd.models.resnet_passport_private import ResNet18Private
+    from oracle.cases import resnet18_config
+    private = net_kind.endswith('v2')
+    kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    torch.manual_seed(3)
+    np.random.seed(3)
+    net = (ResNet18Private if private else ResNet18Passport)(num_classes=10, passport_kwargs=kw).to(DEV)
+    net.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(128, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (128,), generator=g).to(DEV)
+    with torch.no_grad():
+        net(x)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    ce = torch.nn.functional.cross_entropy
+
+    def step(off):
+        if off:
+            monkeypatch.setenv('DEEPIPR_NO_DUAL_TAIL', '1')
+        else:
+            monkeypatch.delenv('DEEPIPR_NO_DUAL_TAIL', raising=False)
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        _lib.profile_enable(True)
+        if private:
+            outs = list(net.forward_dual(x))
+            loss = ce(outs[0], y) + ce(outs[1], y) + sum(m.sign_loss_private.loss for m in net.modules()
+                                                         if hasattr(m, 'sign_loss_private'))
+        else:
+            outs = [net(x)]
+            loss = ce(outs[0], y) + sum(m.sign_loss.loss for m in net.modules()
+                                        if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+        loss.backward()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        got = {'logits%d' % i: o.detach().clone() for i, o in enumerate(outs)}
+        got.update({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        got.update({'buf/' + k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+        return got, int(prof['bn_res_fwd'][1]), int(prof['bn_res_bwd'][1])
+
+    with pinned_miopen():
+        dual, f0, b0 = step(False)
+        separate, f1, b1 = step(True)
+    assert (f1 - f0, b1 - b0) == (2, 2), ((f0, b0), (f1, b1))
+    diff = {k: float((dual[k] - separate[k]).abs().max()) for k in dual if not torch.equal(dual[k], separate[k])}
+    assert not diff, '%d tensors differ: %s' % (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:4])
