@@ -495,13 +495,19 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
     if not graph:
         assert a['outs'][0] == b['outs'][0], (a['outs'][0], b['outs'][0])  # first step: identical forward, bit for bit
     for u, v in zip(a['outs'], b['outs']):
-        assert np.allclose(u, v, rtol=1e-4, atol=1e-5), (u, v)
+        assert np.allclose(u, v, rtol=1e-3 if graph else 1e-4, atol=1e-4 if graph else 1e-5), (u, v)
     for k, v in b['state'].items():
         if k.endswith('num_batches_tracked'):
             assert int(a['state'][k]) == int(v), k
         else:
-            scale = float(v.abs().max()) + 1e-12
-            assert float((a['state'][k] - v).abs().max()) <= 1e-4 * scale + 1e-7, k
+            # three steps at lr 0.01 with gradients of O(10) (sign loss ~30): the association of the two branches' sum
+            # (a few 1e-6 of the gradient scale) shows as ~1e-6 absolute in every parameter
+            # -- and grows by orders of magnitude per step from there (early training, large gradients: 7e-9 after one
+            # step, 8e-6 after three, 4e-5 after seven on the CPU).  The replayed variant has run seven steps by now
+            # (three warm-up steps, the captured one, three replays): its bar is the trajectory tests' one.
+            worst = float((a['state'][k] - v).abs().max())
+            rel, ab = (5e-3, 2e-4) if graph else (1e-4, 5e-5)
+            assert worst <= rel * float(v.abs().max()) + ab, (k, worst)
 
 
 # ----------------------------------------------------------------------------- dual form: two norm layers + tail, one launch
