@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- $CMD --no-kernel-timing > /tmp/pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   # keep the hand-written kernels' rows only (the raw file has every MIOpen / ATen dispatch)
-  (head -1 "$f"; grep -E 'k_bn_res|k_gamma_beta|k_rank2|k_sgd|k_bn_affine|k_bn_walk|k_gn_' "$f") > $GRAFT_REPO_ROOT/gpurun_out/${R}_pmc_${c}_in_situ.csv
+  (head -1 "$f"; grep -E 'k_bn_res|k_bn_dual|k_gamma_beta|k_rank2|k_sgd|k_bn_affine|k_bn_walk|k_gn_' "$f") > $GRAFT_REPO_ROOT/gpurun_out/${R}_pmc_${c}_in_situ.csv
 done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_in_situ.py gpurun_out/${R}_pmc_FETCH_SIZE_in_situ.csv gpurun_out/${R}_pmc_WRITE_SIZE_in_situ.csv gpurun_out/${R}_bench_eager_for_pmc.json > gpurun_out/${R}_pmc_in_situ.json

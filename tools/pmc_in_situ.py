@@ -23,6 +23,8 @@ def family(name):
     m = re.match(r'(k_[a-z0-9_]+)', name)
     if m and m.group(1).startswith('k_sgd_momentum'):
         return 'k_sgd'
+    if m and m.group(1).startswith('k_bn_dual_'):        # a projection block's two norm layers in one launch: accounted
+        return 'k_bn_res_' + m.group(1)[len('k_bn_dual_'):]   # by the library (and bench.py) with the k_bn_res_* family
     return m.group(1) if m else None
 
 
