@@ -246,7 +246,7 @@ class BottleneckPassportBlock(nn.Module):
         if isinstance(self.convbn_3, PASSPORT_TYPES):
             self.convbn_3.ensure_key(out)
         if self.has_projection():
-            pair = dual_tail(self.convbn_2, self.shortcut, out, skip)     # both plain ConvBlocks: one launch for the two
+            pair = dual_tail(self.convbn_3, self.shortcut, out, skip)     # both plain ConvBlocks: one launch for the two
             if pair is not None:                                          # norm layers and the tail
                 return pair
         sc = run_layer(self.shortcut, skip, force_passport, ind) if self.has_projection() else skip
