@@ -218,7 +218,24 @@ def self_launch(argv, n):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault('OMP_NUM_THREADS', '4')
-    return subprocess.call(cmd, env=env)
+    # the ranks live in their own process group and go down with this process: a `timeout` or Ctrl-C aimed at the one
+    # command the user typed must not leave N orphans on the GPUs
+    import signal
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(proc.pid, signum)
+        except ProcessLookupError:
+            pass
+    old = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        return proc.wait()
+    finally:
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
+        if proc.poll() is None:
+            os.killpg(proc.pid, signal.SIGKILL)
 
 
 def dry_run(args):
