@@ -377,34 +377,46 @@ def main():
         from deepipr_amd.experiments.graph_step import GraphedTrainStep
         return GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
 
+    # (launch form, in-launch exchange allowed): with several ranks the forms are tried in this order until one runs
+    # clean on EVERY rank; the last resort gives up the split-channel single-pass kernels (three launches for layers with
+    # fewer channels than CUs) -- e.g. when something else occupies CUs of the device (two processes on one GPU).
     forms = []
     if use_graph:
-        forms = ['staged', 'unstaged'] if (tdist.is_initialized() and not args.unstaged) else ['unstaged']
+        many = tdist.is_initialized()
+        first = 'unstaged' if (args.unstaged or not many) else 'staged'
+        forms = [(first, True)] + ([(first, False), ('unstaged', False)] if many else [])
+    from deepipr_amd.passport_ops import kernels as _k
+    if not _k.sync_user:                                   # the user switched the in-launch exchange off already
+        forms = [(name, False) for name, _s in forms]
+    forms = [f for i, f in enumerate(forms) if f not in forms[:i]]
     # state to return to if a launch form has to be given up after it already ran steps (N > 1 only)
     keep = None
     if len(forms) > 1:
         keep = ({k: v.clone() for k, v in model.state_dict().items()}, opt.flat_buf.clone())
-    use_graph = False
-    for form in forms:
+    use_graph, sync_default = False, _k.sync_user
+    for form, sync_ok in forms:
         err = None
         try:
+            if not sync_ok and _k.sync_user:
+                _k.set_user_sync(False)
             graphed = build(form)
             step = lambda i, g=graphed: g(xs[i % nb], ys[i % nb])
-            if form == 'staged':
+            if len(forms) > 1:
                 # a few replays before the form is accepted: an in-launch exchange that timed out next to a collective
-                # (never seen; staged.py explains why it should not happen) would show here, on any rank
+                # (never seen with one process per GPU; staged.py explains why it should not happen) shows here
                 for i in range(3):
                     step(i)
                 torch.cuda.synchronize()
                 if _exchange_timeouts():
-                    raise RuntimeError('in-launch exchange timed out next to a collective')
+                    raise RuntimeError('an in-launch exchange of the single-pass norm kernels timed out')
         except Exception as exc:                           # capture refused / form unusable
             err = exc
         if everyone(err is None):
-            use_graph, launch_form = True, form
+            use_graph, launch_form = True, form + ('' if sync_ok or not sync_default else ', in-launch exchange off')
             break
-        print('bench.py: launch form %r given up (%s); trying the next one' % (
-            form, 'another rank failed' if err is None else '%s: %s' % (type(err).__name__, err)), file=sys.stderr)
+        print('bench.py: launch form %r (in-launch exchange %s) given up (%s); trying the next one' % (
+            form, 'on' if sync_ok else 'off',
+            'another rank failed' if err is None else '%s: %s' % (type(err).__name__, err)), file=sys.stderr)
         torch.cuda.synchronize()
         if hasattr(graphed, 'close'):
             graphed.close()
@@ -413,7 +425,6 @@ def main():
             with torch.no_grad():
                 model.load_state_dict(keep[0])
                 opt.flat_buf.copy_(keep[1])
-            from deepipr_amd.passport_ops import kernels as _k
             _k.reset_sync_words()
     import torch.distributed as _td
     tdist_on = _td.is_available() and _td.is_initialized()
@@ -514,9 +525,10 @@ def main():
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
                    'launch': (('hipGraph replay of %s; kernel timing from %d eager steps right after the timed region'
                                % ('the whole step' if not tdist_on else ('zero_grad..backward, then one eager '
-                                  'all-reduce + fused SGD' if launch_form == 'unstaged' else 'the staged step '
+                                  'all-reduce + fused SGD' if launch_form.startswith('unstaged') else 'the staged step '
                                   '(backward stages captured back to back, bucket all-reduces on a side stream '
-                                  'behind each stage\'s event, fused SGD)'), sampled))
+                                  'behind each stage\'s event, fused SGD)'), sampled)
+                               + ('; in-launch exchange switched off after a time-out' if 'exchange off' in launch_form else ''))
                               if use_graph else 'eager')},
     }
     STREAMING = {'gn_bwd': 'GroupNorm/InstanceNorm+affine+ReLU backward, register-resident (12 B/elt)',

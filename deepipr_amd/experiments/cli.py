@@ -46,6 +46,9 @@ def make_parser(private):
                    help='(the default on the GPU; kept for compatibility) replay the train step from captured hipGraphs: '
                         'one GPU: the whole step; several: forward + backward in stages, the gradient buckets all-reduced '
                         'between the replays, one fused SGD kernel')
+    p.add_argument('--reproducible', action='store_true', default=False,
+                   help='bit-reproducible steps: MIOpen in immediate mode with its atomic backward-data solver switched '
+                        'off (deepipr_amd/reproducible.py) instead of find mode')
     p.add_argument('--eager', action='store_true', default=False,
                    help='eager dispatch instead of hipGraph replay (several GPUs: gradient exchange launched from '
                         'gradient hooks, overlapped with backward)')

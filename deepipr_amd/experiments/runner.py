@@ -134,7 +134,11 @@ def run(args, private, train_loader=None, valid_loader=None, wm_loader=None):
     device = torch.device(dev_name, local_rank) if dev_name == 'cuda' else torch.device(dev_name)
     if device.type == 'cuda':
         torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True
+    if args.get('reproducible'):
+        from deepipr_amd.reproducible import pin
+        pin()                                       # immediate mode, atomic backward-data solver off
+    else:
+        torch.backends.cudnn.benchmark = True      # MIOpen find mode, as train_v1.py:8
     dataset = args['dataset']
     ncls, size = NUM_CLASSES[dataset], IMAGE_SIZE[dataset]
     lr_config = json.load(open(args['lr_config']))

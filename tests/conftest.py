@@ -19,6 +19,16 @@ if ROOT not in sys.path:
 if 'MIOPEN_USER_DB_PATH' not in os.environ:
     import tempfile
     os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='deepipr_miopen_udb_')
+# An empty database is not enough: the session's OWN find-mode tests fill it again, and when their measurement happens
+# to rank that solver first for a shape a pinned test uses later (ResNet18 V2 at batch 64: layer4.0.convbnrelu_1's
+# backward-data), the pinned test gets the atomic kernel after all -- seen once in six full sessions of round 3, named
+# by tests/test_zz_session_end_gpu.py (the SAME form run twice differed; the kernel list held
+# kernel_grouped_conv_bwd_data_multiple_d_xdl_cshuffle<..., InMemoryDataOperationEnum 1 = atomic add>; first differing
+# module in backward order layer4.0.convbnrelu_1.conv).  So the solver itself is switched off for the test session
+# (deepipr_amd.reproducible.ENV names it; MIOpen reads the variable when it first enumerates solvers).
+from deepipr_amd.reproducible import ENV as _MIOPEN_REPRODUCIBLE_ENV   # noqa: E402  (no torch import, no GPU needed)
+for _k, _v in _MIOPEN_REPRODUCIBLE_ENV.items():
+    os.environ.setdefault(_k, _v)
 
 
 def pytest_configure(config):
