@@ -13,7 +13,11 @@ import torch.nn as nn
 
 
 # Activations smaller than this stay on the library norm + ReLU kernels (override: DEEPIPR_CONVBLOCK_FUSE_MIN).
-FUSE_MIN_ELEMENTS = int(os.environ.get('DEEPIPR_CONVBLOCK_FUSE_MIN', 1 << 20))
+# Measured under the default launch mode (hipGraph replay; tools/gpu_fusemin.sh, profiles/r03_fusemin.log, two
+# alternating repetitions on one MI355X): 2^18 against round 2's 2^20 -- config P shard 3.081 -> 3.016 ms (-2.1 %: all
+# of layer3's ConvBlocks at 32 images per GPU are 2^19 elements), ResNet18 V1 batch 32 -0.5 %, AlexNet V2 batch 64
+# -0.8 %, AlexNet V1 -0.3 %; fusing everything (0) measures the same as 2^18, so the cut only keeps toy shapes away.
+FUSE_MIN_ELEMENTS = int(os.environ.get('DEEPIPR_CONVBLOCK_FUSE_MIN', 1 << 18))
 
 
 def make_norm(norm_type, channels, affine):
