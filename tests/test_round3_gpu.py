@@ -449,7 +449,7 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
 def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
     """ResNet18 V2 (config P shard: batch 32, 100 classes): the layers in front of layer4 run once for both branches
     (models/_builders.shared_trunk) against the two full passes (DEEPIPR_NO_SHARED_TRUNK=1), eagerly and replayed from
-    the whole-step hipGraph: three steps each; logits-derived scalars, every parameter and every buffer (running
+    the whole-step hipGraph (one eager step / seven replayed ones); logits-derived scalars, every parameter and every buffer (running
     statistics after TWO updates per step, num_batches_tracked) agree -- gradients differ only by the association of
     the two branches' sum."""
     from deepipr_amd.experiments.graph_step import GraphedTrainStep
@@ -485,13 +485,13 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
                 step = GraphedTrainStep(train_step_v23, dual, opt, x, y)
                 outs = [tuple(float(v) for v in step(x, y)) for _ in range(3)]
             else:
-                outs = [tuple(float(v) for v in train_step_v23(dual, opt, x, y)) for _ in range(3)]
+                outs = [tuple(float(v) for v in train_step_v23(dual, opt, x, y))]       # ONE step: see the bars below
             torch.cuda.synchronize()
             res[mode] = dict(outs=outs, state={k: v.detach().clone() for k, v in net.state_dict().items()},
                              calls=calls['n'])
     a, b = res['shared'], res['twice']
     if not graph:
-        assert (a['calls'], b['calls']) == (3, 6), (a['calls'], b['calls'])     # the trunk really runs once per step
+        assert (a['calls'], b['calls']) == (1, 2), (a['calls'], b['calls'])     # the trunk really runs once per step
     if not graph:
         assert a['outs'][0] == b['outs'][0], (a['outs'][0], b['outs'][0])  # first step: identical forward, bit for bit
     for u, v in zip(a['outs'], b['outs']):
@@ -502,11 +502,12 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
         if k.endswith('num_batches_tracked'):
             assert int(a['state'][k]) == int(v), k
         else:
-            # three steps at lr 0.01 with gradients of O(10) (sign loss ~30): the association of the two branches' sum
-            # (a few 1e-6 of the gradient scale) shows as ~1e-6 absolute in every parameter
-            # -- and grows by orders of magnitude per step from there (early training, large gradients: 7e-9 after one
-            # step, 8e-6 after three, 4e-5 after seven on the CPU).  The replayed variant has run seven steps by now
-            # (three warm-up steps, the captured one, three replays): its bar is the trajectory tests' one.
+            # The association of the two branches' sum (a few 1e-6 of the gradient scale) is the only difference after
+            # ONE step (eager variant: 1e-8 absolute in the parameters).  From there it grows by orders of magnitude per
+            # step -- early training, gradients of O(10) from a sign loss of ~30: 7e-9 after one step, 8e-6 after three,
+            # 4e-5 after seven on the CPU; 1e-4 after three on the GPU -- so only the one-step comparison is tight.  The
+            # replayed variant has run seven steps by now (three warm-up steps, the captured one, three replays): its bar
+            # is the trajectory tests' one.
             worst = float((a['state'][k] - v).abs().max())
             rel, ab = (5e-3, 2e-4) if graph else (1e-4, 5e-5)
             assert worst <= rel * float(v.abs().max()) + ab, (k, worst)
