@@ -1069,7 +1069,8 @@ class gamma_beta_batch:
     autograd node treats it as its own GEMV's result.  Backward: the layers of one GROUP (`group_of(layer)`: the
     backward stage the layer belongs to, models' backward_stages(); one group without it) leave the rank-2 update of
     the shared weights' gradients -- and handing those gradients to autograd -- to one launch per group (_Rank2Group);
-    a layer alone in its group, or whose convolution runs outside the fused node, does its own as before.  Pairs nobody used are dropped on exit.
+    a layer alone in its group, or whose convolution runs outside the fused node, does its own as before.  Pairs nobody
+    used are dropped on exit.
     DEEPIPR_NO_GEMV_BATCH=1 switches the batching off, DEEPIPR_NO_RANK2_BATCH=1 only the backward part."""
 
     def __init__(self, layers, force_passport=False, ind=0, group_of=None):
