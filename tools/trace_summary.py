@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--top', type=int, default=25)
     ap.add_argument('--out-csv', default=None, help='also write kernel name, calls/step, us/step to this CSV')
     ap.add_argument('--gaps', type=int, default=0, help='also list the N largest idle gaps between consecutive kernels')
+    ap.add_argument('--markers-per-step', type=int, default=1, help='occurrences of the marker kernel per train step '
+                    '(2 for the dual-branch V2 / V3 step: two cross-entropy heads)')
     ap.add_argument('--marker', default=None, help='once-per-step kernel (default: k_ce_finish, else nll_loss_forward)')
     args = ap.parse_args()
     rows = []
@@ -28,11 +30,11 @@ def main():
     rows.sort()
     for marker in ([args.marker] if args.marker else ['k_ce_finish', 'nll_loss_forward']):
         marks = [i for i, r in enumerate(rows) if marker in r[2]]
-        if len(marks) > args.steps:
+        if len(marks) > args.steps * args.markers_per_step:
             break
     else:
         raise SystemExit('only %d marker kernels in the trace' % len(marks))
-    lo, hi = marks[-args.steps - 1], marks[-1]
+    lo, hi = marks[-args.steps * args.markers_per_step - 1], marks[-1]
     win = rows[lo:hi]
     wall = rows[hi][0] - rows[lo][0]
     stats = collections.defaultdict(list)
