@@ -197,10 +197,12 @@ class PassportLayerBase(nn.Module):
         self._pooled.clear()                       # the keys were refilled in place
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, x, force_passport, ind, residual=None):
+    def _forward(self, x, force_passport, ind, residual=None, conv_out=None):
         """The layer; with `residual` (the shortcut of a residual block whose last layer this is) the pair of handles
-        of relu(layer(x) + residual), folded into the layer's own kernels when they take the single-pass form."""
-        y = self._layer(x, force_passport, ind, residual)
+        of relu(layer(x) + residual), folded into the layer's own kernels when they take the single-pass form.
+        conv_out: self.conv(x), already computed by the caller (the two branches of a V2 / V3 dual forward share the
+        data convolution of the first layers behind the point where they part: same input, same weight)."""
+        y = self._layer(x, force_passport, ind, residual, conv_out)
         if residual is None or isinstance(y, tuple):
             return y
         return P.add_relu_fork(y, residual)
@@ -245,20 +247,29 @@ class PassportLayerBase(nn.Module):
             return 'none', inside
         return 'lib', False
 
-    def _layer(self, x, force_passport, ind, residual):
+    def shareable_conv(self, x):
+        """The data convolution may be computed once by the caller and handed to several calls of this layer
+        (`conv_out`): a plain call of the conv module nobody hooked."""
+        c = self.conv
+        return (x.dim() == 4 and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks
+                and not self._forward_hooks and not self._forward_pre_hooks)
+
+    def _layer(self, x, force_passport, ind, residual, conv_out=None):
         self.ensure_key(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
         p_bias = self._use_param(self.bias, force_passport, ind)
         if p_scale != p_bias:                        # mixed (only one of scale / bias learnable): compose the operators
-            x = self.bn(self.conv(x))
+            x = self.bn(self.conv(x) if conv_out is None else conv_out)
             return P.affine_relu(x, self.get_scale(force_passport, ind), self.get_bias(force_passport, ind), relu)
         public = p_scale
         form, inside = self._plan(x, public)
         tail = None
         if form == 'bn' and residual is not None and P.bn_tail_fusable(self.bn, P.conv_out_shape(x, self.conv)):
             tail = residual                          # relu(layer + shortcut) folded into the layer's own kernels
-        if not inside:
+        if conv_out is not None:                     # the caller ran the convolution (shared by two calls)
+            inside, x = False, conv_out
+        elif not inside:
             x = self.conv(x)
         if public:                                   # learnable scale / bias, no sign loss
             if form == 'bn':

@@ -615,11 +615,18 @@ def test_shared_trunk_of_the_dual_forward_equals_two_full_passes(arch, cpu_kerne
         calls = {'n': 0}
         stem_conv = net.convbnrelu_1.conv if arch == 'resnet18' else net.features[0].conv
         stem_conv.register_forward_hook(lambda *_a: calls.__setitem__('n', calls['n'] + 1))
+        # the first private layer behind the split: its data convolution is shared by the two branches as well
+        # (counted by wrapping .forward: a module hook would make the layer keep its convolution to itself)
+        first = (net.layer4[0].convbnrelu_1 if arch == 'resnet18' else net.features[4]).conv
+        inner = first.forward
+        first.forward = lambda inp, _f=inner: (calls.__setitem__('first', calls.get('first', 0) + 1), _f(inp))[1]
         train_step_v23(DualBranch(net), opt, x, y)
         res[mode] = dict(logits=seen, grads={k: p.grad.clone() for k, p in net.named_parameters()},
-                         state={k: v.clone() for k, v in net.state_dict().items()}, stem_calls=calls['n'])
+                         state={k: v.clone() for k, v in net.state_dict().items()}, stem_calls=calls['n'],
+                         first_calls=calls.get('first', 0))
     a, b = res['shared'], res['twice']
     assert (a['stem_calls'], b['stem_calls']) == (1, 2)                  # the trunk really ran once
+    assert (a['first_calls'], b['first_calls']) == (1, 2)               # and so did the first convolution behind the split
     assert len(a['logits']) == len(b['logits']) == 2                    # the net's forward hooks: two calls
     for u, v in zip(a['logits'], b['logits']):
         assert torch.equal(u, v)
