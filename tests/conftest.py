@@ -49,3 +49,45 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def _accepts_call_of(new, old):
+    """Can `new` be called the way `old` is: with as many positional arguments as `old` declares (its defaults included)
+    and with every keyword `old` declares?  Only plain python callables on both sides are judged."""
+    import inspect
+    try:
+        so, sn = inspect.signature(old), inspect.signature(new)
+    except (TypeError, ValueError):
+        return True
+    P = inspect.Parameter
+    if any(p.kind in (P.VAR_POSITIONAL,) for p in sn.parameters.values()):
+        return True
+    pos_old = [p for p in so.parameters.values() if p.kind in (P.POSITIONAL_ONLY, P.POSITIONAL_OR_KEYWORD)]
+    pos_new = [p for p in sn.parameters.values() if p.kind in (P.POSITIONAL_ONLY, P.POSITIONAL_OR_KEYWORD)]
+    if len(pos_new) < len(pos_old):
+        return False
+    required_new = [p for p in pos_new if p.default is P.empty]
+    return len(required_new) <= len(pos_old)
+
+
+@pytest.fixture(autouse=True)
+def _monkeypatch_arity_guard(monkeypatch):
+    """A test double for a PRODUCT function must accept every call the product makes of the real one.  Round 3 ended red
+    on exactly that: the product grew a sixth positional argument (PassportLayerBase._layer, conv_out) and a test's
+    five-argument replacement raised TypeError deep inside a forward pass.  monkeypatch.setattr now refuses such a
+    replacement at patch time, naming both signatures (CPU and GPU sessions alike); tests/test_test_doubles.py is the
+    static, CPU-side form of the same check."""
+    import inspect
+    real = monkeypatch.setattr
+
+    def checked(*args, **kwargs):
+        if len(args) >= 3 and isinstance(args[1], str) and not isinstance(args[0], str):
+            target, name, value = args[:3]
+            old = getattr(target, name, None)
+            if inspect.isfunction(old) and inspect.isfunction(value) and not _accepts_call_of(value, old):
+                raise TypeError('monkeypatch.setattr(%s, %r): the replacement %s%s cannot take the calls made of %s%s'
+                                % (getattr(target, '__name__', target), name, value.__name__, inspect.signature(value),
+                                   old.__qualname__, inspect.signature(old)))
+        return real(*args, **kwargs)
+    monkeypatch.setattr = checked
+    yield

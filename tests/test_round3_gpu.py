@@ -178,8 +178,8 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(private, monkeypatc
             gates[id(m)] = gate(near[name], torch.float32)
     inner = PassportLayerBase._layer
 
-    def gated_layer(self, x_in, force_passport, ind, residual):
-        out = inner(self, x_in, force_passport, ind, residual)
+    def gated_layer(self, x_in, force_passport, ind, residual, conv_out=None):
+        out = inner(self, x_in, force_passport, ind, residual, conv_out)
         g = gates.get(id(self))
         return out if g is None else g(self, None, out)
     monkeypatch.setattr(PassportLayerBase, '_layer', gated_layer)
