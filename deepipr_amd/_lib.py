@@ -88,13 +88,15 @@ SIGNATURES = {
                                        _vp]),
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
+    'deepipr_conv_wgrad_workspace_bytes': (_sz, [_int] * 9),
+    'deepipr_conv_wgrad': (_int, [_f32p, _f32p, _f32p] + [_int] * 9 + [_f32p, _f32p, _f64p, _vp, _sz, _vp]),
 }
 # exported by the measurement / test build only (libdeepipr_hip_trace.so, DEEPIPR_LIB=...): bound when present
 TEST_HOOK_SIGNATURES = {
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_debug_trace': (_int, [_vp]),
 }
-ABI_VERSION = 6
+ABI_VERSION = 7
 SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
@@ -158,7 +160,7 @@ def check(rc, what):
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
-                   'bn_res_bwd', 'gn_fwd', 'gn_bwd']
+                   'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce']
 
 
 class ExternalEvent:

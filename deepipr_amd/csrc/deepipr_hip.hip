@@ -4030,3 +4030,67 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// data convolution: weight gradient on the fp32 matrix cores (kernels and planner: deepipr_conv.inc)
+// =============================================================================================
+namespace {
+#include "deepipr_conv.inc"
+
+template <class C>
+void launch_wgrad(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
+                  hipStream_t st) {
+    const int grid = p.splits * p.tiles_co * p.tiles_ci;
+    DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad<C>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H, p.tiles_co, p.tiles_ci,
+                   p.chunks, p.chunks_per_split);
+}
+}  // namespace
+
+extern "C" {
+
+size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, int kh, int kw, int stride, int pad) {
+    return plan_wgrad(N, Ci, Co, H, W, kh, kw, stride, pad).workspace;
+}
+
+int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci, int Co, int H, int W, int kh, int kw,
+                       int stride, int pad, const float *dgamma, const float *dbeta, const double *m, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    if (!x || !dy || !dW) return fail(DEEPIPR_EINVAL, "conv_wgrad: null pointer");
+    const WgradPlan p = plan_wgrad(N, Ci, Co, H, W, kh, kw, stride, pad);
+    if (!p.cfg)
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: only 3x3 stride-1 pad-1 convolutions with Ci, Co multiples of 64 on "
+                    "4/8/16/32-wide maps (use the library's weight gradient)");
+    if (!workspace || workspace_bytes < p.workspace) return fail(DEEPIPR_EINVAL, "conv_wgrad: workspace too small");
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return fail(DEEPIPR_EINVAL, "conv_wgrad: pointers must be 16-byte aligned");
+    const bool rank2 = dgamma || dbeta || m;
+    if (rank2 && !(dgamma && dbeta && m)) return fail(DEEPIPR_EINVAL, "conv_wgrad: dgamma, dbeta and m go together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *part = static_cast<float *>(workspace);
+    {
+        ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
+        prof.bytes = 2.0 * Co * Ci * 9.0 * N * H * W;          // FLOPs, not bytes: this kernel's roofline is the MFMA peak
+        switch (p.cfg) {
+            case 32: launch_wgrad<WgCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 16: launch_wgrad<WgCfg<16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 8: launch_wgrad<WgCfg<8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            default: launch_wgrad<WgCfg<4, 4, 2>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+        }
+    }
+    const int tiles = p.tiles_co * p.tiles_ci;
+    ProfScope prof(DEEPIPR_K_CONV_WGRAD_REDUCE, st);
+    prof.bytes = 4.0 * (static_cast<double>(p.splits) + 1.0) * tiles * kWgTile;
+#define DEEPIPR_WGRAD_REDUCE(SG, GRID, BLOCK)                                                                          \
+    do {                                                                                                              \
+        if (rank2) DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, true>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,    \
+                                  p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                     \
+        else DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, false>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,         \
+                            p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                           \
+    } while (0)
+    if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, tiles * 144, 1024);
+    else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, tiles * 144, 256);
+    else DEEPIPR_WGRAD_REDUCE(1, tiles * 36, 256);
+#undef DEEPIPR_WGRAD_REDUCE
+    return check_launch("conv_wgrad");
+}
+
+}  // extern "C"

@@ -15,7 +15,10 @@ from deepipr_amd.models._builders import (PASSPORT_TYPES, conv_factory, ind_matt
                                           trunk_sharing_enabled)
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
-from deepipr_amd.passport_ops import gamma_beta_batch, stage_groups
+from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, stage_groups
+
+_CUT = 5            # features[_CUT]'s input is the activation backward_stages() cuts the staged backward at
+_SHARED_CONV = os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'      # read once, at import (A/B switch)
 
 _WIDTHS = {0: 64, 2: 192, 4: 384, 5: 256, 6: 256}
 _POOL_AT = (1, 3, 7)
@@ -63,12 +66,12 @@ class AlexNetPassport(nn.Module):
     def backward_stages(self):
         """Stages of the staged data-parallel backward (experiments/staged.py), last layers first: the classifier and
         features 5-6 (the larger half of the CIFAR net's parameters), then everything before."""
-        return [('features.5', list(self.features[5:]) + [self.classifier]), (None, list(self.features[:5]))]
+        return [('features.%d' % _CUT, list(self.features[_CUT:]) + [self.classifier]), (None, list(self.features[:_CUT]))]
 
     def _run_features(self, x, lo, hi, force_passport, ind):
         for i in range(lo, hi):
-            if i == 5:
-                x = cuts.mark('features.5', x)
+            if i == _CUT:
+                x = cuts.mark('features.%d' % _CUT, x)
             x = run_layer(self.features[i], x, force_passport, ind)
         return x
 
@@ -91,9 +94,12 @@ class AlexNetPassport(nn.Module):
         layers = [m for m in self.features if isinstance(m, PASSPORT_TYPES)] if x.is_cuda else ()
         # the first layer behind the split convolves the same input with the same weight in both branches: shared too
         first, conv_out = self.features[split] if split < n else None, None
-        if (isinstance(first, PassportPrivateBlock) and first.shareable_conv(x) and split != 5
-                and os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'):
-            conv_out = first.conv(x)
+        # ... unless the branches part exactly at the staged backward's cut (features[_CUT]): _run_features marks the cut on
+        # the layer's INPUT, per branch; a convolution computed here, in front of that mark, would tie the two stages
+        # together through its autograd node.  The layer then convolves once per branch, as without sharing
+        # (tests/test_host_logic.py::test_alexnet_split_at_the_stage_cut_does_not_share_the_convolution).
+        if (isinstance(first, PassportPrivateBlock) and first.shareable_conv(x) and split != _CUT and _SHARED_CONV):
+            conv_out = conv2d(first.conv, x)
         outs = []
         for ind in (0, 1):                               # public branch first: the reference's order of norm updates
             with gamma_beta_batch(layers, force_passport, ind, stage_groups(self)):

@@ -270,7 +270,7 @@ class PassportLayerBase(nn.Module):
         if conv_out is not None:                     # the caller ran the convolution (shared by two calls)
             inside, x = False, conv_out
         elif not inside:
-            x = self.conv(x)
+            x = P.conv2d(self.conv, x)
         if public:                                   # learnable scale / bias, no sign loss
             if form == 'bn':
                 return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail)

@@ -59,7 +59,8 @@ class ConvBlock(nn.Module):
         return y if isinstance(y, tuple) else (y, y)
 
     def forward(self, x, _residual=None, _fork=False):
-        x = self.conv(x)
+        from deepipr_amd import passport_ops as P
+        x = P.conv2d(self.conv, x)
         if (self.fuse_norm and x.is_cuda and x.numel() >= FUSE_MIN_ELEMENTS and isinstance(self.bn, nn.BatchNorm2d)
                 and self.bn.affine and self.bn.momentum is not None and x.dtype == torch.float32):
             from deepipr_amd import passport_ops as P
@@ -98,5 +99,5 @@ def dual_tail(main, short, x, skip):
         return None
     if not P.bn_dual_tail_usable(main.bn, short.bn, shape):
         return None
-    return P.bn_dual_tail(main.conv(x), short.conv(skip), main.bn, short.bn, main.relu is not None,
+    return P.bn_dual_tail(P.conv2d(main.conv, x), P.conv2d(short.conv, skip), main.bn, short.bn, main.relu is not None,
                           short.relu is not None)

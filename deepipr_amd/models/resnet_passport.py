@@ -18,7 +18,10 @@ from deepipr_amd.models._builders import ind_matters, shared_trunk, trunk_sharin
 from deepipr_amd.models.layers.conv2d import dual_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
-from deepipr_amd.passport_ops import gamma_beta_batch, stage_groups
+from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, stage_groups
+
+
+_SHARED_CONV = os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'      # read once, at import (A/B switch)
 
 
 class BasicPassportBlock(nn.Module):
@@ -67,7 +70,7 @@ class BasicPassportBlock(nn.Module):
         only from the affine on), None for the others."""
         def one(layer, inp):
             if isinstance(layer, PassportPrivateBlock) and layer.shareable_conv(inp):
-                return layer.conv(inp)
+                return conv2d(layer.conv, inp)
             return None
         return one(self.convbnrelu_1, x), (one(self.shortcut, skip) if self.has_projection() else None)
 
@@ -206,7 +209,7 @@ class ResNetPassport(nn.Module):
         # the first layers behind the split see the same input in both branches and convolve it with the same weight:
         # that convolution (and its backward: one pass with the branches' summed gradient) is shared as well
         preconv = None
-        if split < len(blocks) and hasattr(blocks[split][2], 'shared_convs') and os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1':
+        if split < len(blocks) and hasattr(blocks[split][2], 'shared_convs') and _SHARED_CONV:
             preconv = blocks[split][2].shared_convs(out, skip)
             if preconv[0] is None and preconv[1] is None:
                 preconv = None

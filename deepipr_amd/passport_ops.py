@@ -631,6 +631,38 @@ class HipKernels:
                                                 lse.data_ptr(), n, c, dlogits.data_ptr(), _stream(dev)), 'ce_bwd')
         return dlogits
 
+    # ---- data convolution: weight gradient on the fp32 matrix cores (include/deepipr_hip.h: deepipr_conv_wgrad) ----
+    _wgrad_ws = {}
+
+    def conv_wgrad_workspace(self, n, ci, co, h, w, kh, kw, stride, pad):
+        """Bytes of split-K workspace deepipr_conv_wgrad needs for this problem; 0 = shape outside the kernel (the
+        caller keeps the library's weight gradient)."""
+        key = (n, ci, co, h, w, kh, kw, stride, pad)
+        v = self._wgrad_ws.get(key)
+        if v is None:
+            v = self._wgrad_ws[key] = int(_lib.lib().deepipr_conv_wgrad_workspace_bytes(*key))
+        return v
+
+    def conv_wgrad(self, x, dy, wshape, stride, pad, dgamma=None, dbeta=None, m=None):
+        """dW of conv(x, W) for upstream gradient dy, or None when the shape is outside the kernel.  With dgamma /
+        dbeta / m the passport branch's rank-2 term is added in the same pass (deepipr_gamma_beta_bwd_acc's result)."""
+        n, ci, h, w = x.shape
+        co, _ci, kh, kw = wshape
+        if tuple(dy.shape) != (n, co, h, w) or _ci != ci:
+            return None
+        nbytes = self.conv_wgrad_workspace(n, ci, co, h, w, kh, kw, stride, pad)
+        if not nbytes:
+            return None
+        dev = _chk(x, dy, dgamma, dbeta, m)
+        st = _stream(dev)
+        ws = self._scratch(dev, ('wgrad', st), nbytes)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, h, w, kh, kw,
+                                                    stride, pad, _p(dgamma), _p(dbeta), _p(m), ws, nbytes, st),
+                       'conv_wgrad')
+        return dw
+
     def sgd_chunk(self):
         return _lib.lib().deepipr_sgd_momentum_chunk()
 
@@ -778,23 +810,85 @@ def _conv_fwd(x_in, w, stride, pad):
     return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
 
 
+# The weight gradient of the data convolution: this library's fp32-MFMA kernel (deepipr_conv_wgrad) wherever its shapes
+# reach -- NCHW in, OIHW out, no layout shims, bit-reproducible -- the vendor library's otherwise.
+# DEEPIPR_OWN_WGRAD=0 switches it off (A/B, triage).
+OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0'
+
+
+def _own_wgrad(x_in, w, stride, pad):
+    if not (OWN_WGRAD and x_in.is_cuda and x_in.dtype == torch.float32 and x_in.dim() == 4 and w.dim() == 4):
+        return False
+    n, ci, h, wd = x_in.shape
+    return bool(kernels.conv_wgrad_workspace(n, ci, w.shape[0], h, wd, w.shape[2], w.shape[3], stride, pad))
+
+
+def _conv_dgrad(dconv, x_in, w, stride, pad):
+    return torch.ops.aten.convolution_backward(dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0],
+                                               1, [True, False, False])[0]
+
+
 def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
-    """Backward of the data convolution that ran inside a fused passport node: MIOpen's dgrad / wgrad, then the passport
-    branch's rank-2 update added INTO that wgrad (deepipr_gamma_beta_bwd_acc) -- or, with `defer` = (share, index), left
-    to the layer group's one launch (_Rank2Group), which is handed the wgrad buffer.  -> dx_in, dW."""
+    """Backward of the data convolution that ran inside a fused passport node.  -> dx_in, dW, deferred.
+    Own weight-gradient kernel (deepipr_conv_wgrad): MIOpen's dgrad, then the wgrad with the passport branch's rank-2
+    term added in its reduction pass -- the shared weight's three-way gradient is complete when it is first written.
+    Otherwise MIOpen's dgrad / wgrad, then the rank-2 update added INTO that wgrad (deepipr_gamma_beta_bwd_acc) -- or,
+    with `defer` = (share, index), left to the layer group's one launch (_Rank2Group), which is handed the wgrad buffer
+    (deferred = True: the caller sends dgamma / dbeta to the group node)."""
     need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     if not (need_dx or need_dw):                      # frozen first layer: nothing flows further
-        return None, None
+        return None, None, False
+    if need_dw and _own_wgrad(x_in, w, stride, pad):
+        dconv = dconv.contiguous()
+        dx = _conv_dgrad(dconv, x_in, w, stride, pad) if need_dx else None
+        return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
     dx, dw, _ = torch.ops.aten.convolution_backward(
         dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
     if need_dw:
         dw = dw.contiguous()
         if defer is not None:
             defer[0].wgrads[defer[1]] = dw               # completed and handed to autograd by the group node
-            dw = None
-        else:
-            dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw)
-    return dx, dw
+            return dx, None, True
+        dw = kernels.gamma_beta_bwd_acc(dg, db, m, dw)
+    return dx, dw, False
+
+
+class _Conv2dOwnWgrad(torch.autograd.Function):
+    """`conv(x)` of a plain bias-free convolution (models/layers/conv2d.py:31; passportconv2d.py:218 when the data
+    convolution runs outside the fused node): forward and backward-data stay the vendor library's, the weight gradient
+    is deepipr_conv_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, pad)
+        ctx.set_materialize_grads(False)
+        return _conv_fwd(x, w, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.geom
+        if dy is None:
+            return None, None, None, None
+        dy = dy.contiguous()
+        dx = _conv_dgrad(dy, x, w, stride, pad) if ctx.needs_input_grad[0] else None
+        dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+def conv2d(conv, x):
+    """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked whose weight gradient this library computes itself
+    goes through _Conv2dOwnWgrad; anything else is the module call."""
+    if (OWN_WGRAD and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+            and conv.padding_mode == 'zeros' and conv.stride[0] == conv.stride[1]
+            and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
+            and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or conv._backward_pre_hooks)
+            and type(conv) is torch.nn.Conv2d and torch.is_grad_enabled() and conv.weight.requires_grad
+            and _own_wgrad(x, conv.weight, conv.stride[0], conv.padding[0])):
+        return _Conv2dOwnWgrad.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+    return conv(x)
 
 
 class _Rank2Share:
@@ -885,7 +979,7 @@ class _PassportLayer(torch.autograd.Function):
                                               _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
                                               None if x_in is not None else weight.shape, relu)
         if x_in is not None:
-            dx, dw = _conv_bwd_acc(ctx, dx, x_in, weight, stride, pad, dg, db, m)
+            dx, dw, _ = _conv_bwd_acc(ctx, dx, x_in, weight, stride, pad, dg, db, m)
         dsk = dk = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             dsk, dk = kernels.gamma_beta_dkey(dg, db, weight, key_shape, stride, pad)
@@ -970,7 +1064,8 @@ class _PassportBNLayer(torch.autograd.Function):
             # the group node (_Rank2Group), which runs once all its layers have been here
             deferred = (ctx.defer is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[4]
                         and ctx.needs_input_grad[5])
-            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m, defer=ctx.defer if deferred else None)
+            dx, dw, deferred = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m,
+                                             defer=ctx.defer if deferred else None)
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)
@@ -1218,7 +1313,7 @@ class _PassportGNLayer(torch.autograd.Function):
                                                  _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
                                                  None if (w is None or x_in is not None) else w.shape, relu, groups)
         if x_in is not None:
-            dx, dw = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m)
+            dx, dw, _ = _conv_bwd_acc(ctx, dx, x_in, w, stride, pad, dg, db, m)
         dsk = dk = None
         if w is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             dsk, dk = kernels.gamma_beta_dkey(dg, db, w, key_shape, stride, pad)

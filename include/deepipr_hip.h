@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 6
+#define DEEPIPR_ABI_VERSION 7
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -79,7 +79,9 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_BN_RES_BWD 18
 #define DEEPIPR_K_GN_FWD 19
 #define DEEPIPR_K_GN_BWD 20
-#define DEEPIPR_PROFILE_KERNELS 21
+#define DEEPIPR_K_CONV_WGRAD 21         /* `bytes` of this slot are FLOPs: its roofline is the fp32 MFMA peak */
+#define DEEPIPR_K_CONV_WGRAD_REDUCE 22
+#define DEEPIPR_PROFILE_KERNELS 23
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -400,6 +402,26 @@ int deepipr_relu_bwd(const float *dy, const float *out, float *dx, size_t n, voi
  * consumers (the next block's first conv and its shortcut), whose gradients autograd would otherwise add in a
  * separate kernel (12 B/element more).  dy2 == NULL is deepipr_relu_bwd. */
 int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float *dx, size_t n, void *stream);
+
+/* ------------------------------------------------------------------ data convolution: weight gradient
+ * dW[co][ci][r][s] = sum_{n,oh,ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + r - pad][ow*stride + s - pad]
+ * on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation in a fixed order --
+ * bit-reproducible, no atomics), straight from the NCHW tensors: no layout conversion of x / dy / dW, no zero fill.
+ * Split K over workgroups leaves partial tiles in `workspace`; a second launch sums them in split order and writes dW
+ * (OIHW).  With dgamma / dbeta / m (all three or none) that launch also adds the passport branch's term,
+ * dW[co][k] += dgamma[co] * m[0][k] + dbeta[co] * m[1][k]  (deepipr_gamma_beta_bwd_acc's arithmetic), so the shared
+ * weight's three-way gradient is complete when it is first written.
+ * Supported: 3x3, stride 1, pad 1, Ci and Co multiples of 64, maps 4 / 8 / 16 / 32 wide (H a multiple of the row band:
+ * 4 / 8 / 4 / 2 rows; N even for 4-wide maps).  Anything else: deepipr_conv_wgrad_workspace_bytes returns 0 and
+ * deepipr_conv_wgrad returns DEEPIPR_EUNSUPPORTED without enqueuing anything -- the caller keeps the library's wgrad.
+ * replaces: the weight half of aten::convolution_backward behind `self.conv(x)`,
+ *           models/layers/passportconv2d.py:218 (private twin :215), models/layers/conv2d.py:31 -- MIOpen's
+ *           igemm_wrw_gtcx35_nhwc + batched_transpose_* + SubTensorOpWithScalar1d (profiles/r03_steady_state.md).
+ * x [N][Ci][H][W]   dy [N][Co][H][W]   dW [Co][Ci][3][3]   m [2][Ci*9] double   all pointers 16-byte aligned */
+size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, int kh, int kw, int stride, int pad);
+int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci, int Co, int H, int W, int kh, int kw,
+                       int stride, int pad, const float *dgamma, const float *dbeta, const double *m, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

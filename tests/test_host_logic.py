@@ -643,3 +643,39 @@ def test_shared_trunk_of_the_dual_forward_equals_two_full_passes(arch, cpu_kerne
     # and the statistics did move twice: one update would leave running_mean at 0.1 * batch mean, two at 0.19 *
     for name in (shared_bn, branch_bn):
         assert float(a['state'][name + '.running_mean'].abs().max()) > 0
+
+
+def test_alexnet_split_at_the_stage_cut_does_not_share_the_convolution(cpu_kernels):
+    """AlexNet V2 whose FIRST private passport layer is features[5] -- exactly where backward_stages() cuts the staged
+    backward (alexnet_passport._CUT).  The cut is marked on that layer's input, per branch; a convolution shared in front
+    of the mark would tie the two stages' autograd graphs together, so forward_dual keeps one convolution per branch there
+    (the trunk in front of it is still shared).  Equal to the two full passes."""
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models import alexnet_passport
+    from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+    from oracle.cases import alexnet_config
+    cfg = dict(alexnet_config())
+    cfg['4'] = False                                        # passport layers: features 5 and 6 only
+    assert cfg['5'] and cfg['6'] and alexnet_passport._CUT == 5
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': 0.1})
+    torch.manual_seed(3)
+    np.random.seed(3)
+    net = AlexNetPassportPrivate(3, 10, kw)
+    net.train()
+    x = torch.randn(4, 3, 32, 32)
+    with torch.no_grad():
+        net(x)
+    calls = {'first': 0, 'stem': 0}
+    first = net.features[5].conv
+    inner = first.forward
+    first.forward = lambda inp, _f=inner: (calls.__setitem__('first', calls['first'] + 1), _f(inp))[1]
+    stem = net.features[0].conv
+    inner0 = stem.forward
+    stem.forward = lambda inp, _f=inner0: (calls.__setitem__('stem', calls['stem'] + 1), _f(inp))[1]
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    a0, a1 = net.forward_dual(x)
+    assert calls == {'first': 2, 'stem': 1}                 # trunk shared, the convolution at the cut is not
+    net.load_state_dict(state)
+    b0, b1 = net(x, ind=0), net(x, ind=1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
