@@ -4058,8 +4058,8 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     if (!x || !dy || !dW) return fail(DEEPIPR_EINVAL, "conv_wgrad: null pointer");
     const WgradPlan p = plan_wgrad(N, Ci, Co, H, W, kh, kw, stride, pad);
     if (!p.cfg)
-        return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: only 3x3 stride-1 pad-1 convolutions with Ci, Co multiples of 64 on "
-                    "4/8/16/32-wide maps (use the library's weight gradient)");
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: only 3x3 pad-1 convolutions of stride 1 / 2 with Ci, Co multiples of 64 "
+                    "and output maps 4/8/16/32 (stride 2: 4/8/16) wide (use the library's weight gradient)");
     if (!workspace || workspace_bytes < p.workspace) return fail(DEEPIPR_EINVAL, "conv_wgrad: workspace too small");
     if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return fail(DEEPIPR_EINVAL, "conv_wgrad: pointers must be 16-byte aligned");
     const bool rank2 = dgamma || dbeta || m;
@@ -4068,12 +4068,15 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     float *part = static_cast<float *>(workspace);
     {
         ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
-        prof.bytes = 2.0 * Co * Ci * 9.0 * N * H * W;          // FLOPs, not bytes: this kernel's roofline is the MFMA peak
+        prof.bytes = 2.0 * Co * Ci * 9.0 * N * (H / stride) * (W / stride);      // FLOPs, not bytes: this kernel's roofline is the MFMA peak
         switch (p.cfg) {
-            case 32: launch_wgrad<WgCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
-            case 16: launch_wgrad<WgCfg<16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
-            case 8: launch_wgrad<WgCfg<8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
-            default: launch_wgrad<WgCfg<4, 4, 2>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 132: launch_wgrad<WgCfg<1, 32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 116: launch_wgrad<WgCfg<1, 16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 108: launch_wgrad<WgCfg<1, 8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 104: launch_wgrad<WgCfg<1, 4, 4, 2>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 216: launch_wgrad<WgCfg<2, 16, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 208: launch_wgrad<WgCfg<2, 8, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            default: launch_wgrad<WgCfg<2, 4, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
         }
     }
     const int tiles = p.tiles_co * p.tiles_ci;

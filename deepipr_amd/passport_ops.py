@@ -648,7 +648,7 @@ class HipKernels:
         dbeta / m the passport branch's rank-2 term is added in the same pass (deepipr_gamma_beta_bwd_acc's result)."""
         n, ci, h, w = x.shape
         co, _ci, kh, kw = wshape
-        if tuple(dy.shape) != (n, co, h, w) or _ci != ci:
+        if _ci != ci or tuple(dy.shape) != (n, co, (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1):
             return None
         nbytes = self.conv_wgrad_workspace(n, ci, co, h, w, kh, kw, stride, pad)
         if not nbytes:

@@ -121,3 +121,19 @@ def test_integration_stub_matches_the_abi():
     # every entry point the stub calls is declared
     for name in set(re.findall(r'_L\.(deepipr_[a-z0-9_]+)', text)):
         assert name in _lib.SIGNATURES, name
+
+
+def test_conv_wgrad_planner_and_argument_checks_without_a_gpu():
+    """Shapes outside the weight-gradient kernel report a zero workspace (the caller keeps the library's wgrad); argument
+    validation happens before any HIP call."""
+    handle = _lib.lib()
+    ws = handle.deepipr_conv_wgrad_workspace_bytes
+    assert ws(128, 64, 64, 32, 32, 3, 3, 1, 1) > 0 and ws(32, 512, 512, 4, 4, 3, 3, 1, 1) > 0
+    assert ws(128, 64, 128, 32, 32, 3, 3, 2, 1) > 0 and ws(32, 256, 512, 8, 8, 3, 3, 2, 1) > 0           # stride 2
+    for bad in [(128, 3, 64, 32, 32, 3, 3, 1, 1), (128, 64, 64, 64, 64, 3, 3, 2, 1), (128, 64, 64, 32, 32, 3, 3, 3, 1), (128, 64, 64, 32, 32, 1, 1, 1, 0),
+                (128, 64, 64, 14, 14, 3, 3, 1, 1), (128, 64, 80, 8, 8, 3, 3, 1, 1), (3, 64, 64, 4, 4, 3, 3, 1, 1),
+                (0, 64, 64, 8, 8, 3, 3, 1, 1)]:
+        assert ws(*bad) == 0, bad
+    assert ws(128, 64, 64, 32, 32, 3, 3, 1, 1) % (64 * 64 * 9 * 4) == 0          # whole partial tiles
+    rc = handle.deepipr_conv_wgrad(None, None, None, 128, 64, 64, 32, 32, 3, 3, 1, 1, None, None, None, None, 0, None)
+    assert rc == -1 and b'conv_wgrad' in handle.deepipr_last_error()

@@ -1,0 +1,140 @@
+"""deepipr_conv_wgrad -- the data convolution's weight gradient on the fp32 matrix cores -- against the oracle.
+
+The reference op is the weight half of the autograd backward of `self.conv(x)` (models/layers/passportconv2d.py:218,
+models/layers/conv2d.py:31), i.e. ATen's convolution_backward; the oracle here is that same ATen op evaluated in
+float64 (oracle/torch_ref.py composes its layers from it).  Bar: 1e-5 of the gradient's scale (fp32 accumulation over up
+to 131 072 products; measured 3-6e-7, the vendor library's own fp32 result sits at 4e-7 - 1e-6), bit-reproducible."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def K():
+    from deepipr_amd.passport_ops import kernels
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    return kernels
+
+
+def _ref(x, dy, wshape, stride=1, pad=1):
+    # (the oracle: ATen's own convolution_backward in float64)
+    w = torch.zeros(wshape, dtype=torch.float64, device=x.device)
+    return torch.ops.aten.convolution_backward(dy.double(), x.double(), w, None, [stride, stride], [pad, pad], [1, 1],
+                                               False, [0, 0], 1, [False, True, False])[1]
+
+
+def _rand(shape, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randn(shape, generator=g).to(DEV)
+
+
+# (N, Ci, Co, H, W): every map width of the kernel; one tile / many tiles; Ci != Co; batch sizes that leave the last
+# split ragged (chunks not a multiple of the split count); the config R and config P shard shapes of ResNet18's layers
+SHAPES = [
+    (128, 64, 64, 32, 32), (32, 64, 64, 32, 32), (3, 64, 64, 32, 32),
+    (128, 128, 128, 16, 16), (5, 64, 128, 16, 16), (32, 128, 128, 16, 16),
+    (128, 256, 256, 8, 8), (7, 256, 128, 8, 8), (32, 256, 256, 8, 8),
+    (128, 512, 512, 4, 4), (2, 512, 512, 4, 4), (32, 512, 512, 4, 4), (6, 128, 192, 4, 4),
+    (2, 64, 64, 8, 32), (4, 64, 64, 16, 4),
+    # stride 2 (the first convolution of layer2 / 3 / 4): (N, Ci, Co, H, W of the INPUT, 2)
+    (128, 64, 128, 32, 32, 2), (5, 64, 64, 32, 32, 2), (128, 128, 256, 16, 16, 2), (3, 128, 64, 16, 16, 2),
+    (128, 256, 512, 8, 8, 2), (1, 256, 64, 8, 8, 2), (2, 64, 64, 16, 32, 2),
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_wgrad_matches_the_float64_oracle_and_is_bit_reproducible(K, shape):
+    n, ci, co, h, w = shape[:5]
+    st = shape[5] if len(shape) > 5 else 1
+    x, dy = _rand((n, ci, h, w), 1 + n + ci), _rand((n, co, h // st, w // st), 2 + n + co)
+    got = K.conv_wgrad(x, dy, (co, ci, 3, 3), st, 1)
+    assert got is not None and got.shape == (co, ci, 3, 3) and got.is_contiguous()
+    ref = _ref(x, dy, (co, ci, 3, 3), st)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * scale
+    again = K.conv_wgrad(x, dy, (co, ci, 3, 3), st, 1)
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize('st', [1, 2])
+def test_wgrad_sees_the_zero_padding_and_every_tap(K, st):
+    """One-hot dy / x: every dW entry is a single product, so a wrong tap offset, a halo column that is not zero or a
+    row band that leaks into its neighbour shows as an exact mismatch."""
+    n, c, h = 2, 64, 8 * st
+    ho = h // st
+    x = torch.zeros(n, c, h, h, device=DEV)
+    dy = torch.zeros(n, c, ho, ho, device=DEV)
+    rs = np.random.RandomState(0)
+    for _ in range(60):
+        x[rs.randint(n), rs.randint(c), rs.choice([0, h - 1, rs.randint(h)]), rs.choice([0, h - 1, rs.randint(h)])] = float(rs.randint(1, 9))
+        dy[rs.randint(n), rs.randint(c), rs.choice([0, ho - 1, rs.randint(ho)]), rs.choice([0, ho - 1, rs.randint(ho)])] = float(rs.randint(1, 9))
+    got = K.conv_wgrad(x, dy, (c, c, 3, 3), st, 1)
+    ref = _ref(x, dy, (c, c, 3, 3), st)
+    assert float(ref.abs().sum()) > 0
+    assert torch.equal(got.double(), ref)                               # small integers: exact in fp32
+
+
+def test_rank2_term_fused_into_the_reduction_equals_the_separate_update(K):
+    """The passport branch's weight-gradient term added in the reduction pass is, bit for bit, deepipr_gamma_beta_bwd_acc
+    applied to the plain weight gradient."""
+    n, c, h = 16, 512, 4
+    x, dy = _rand((n, c, h, h), 5), _rand((n, c, h, h), 6)
+    dg, db = _rand((c,), 7), _rand((c,), 8)
+    m = torch.rand(2, c * 9, dtype=torch.float64, device=DEV) * 2 - 1
+    fused = K.conv_wgrad(x, dy, (c, c, 3, 3), 1, 1, dg, db, m)
+    plain = K.conv_wgrad(x, dy, (c, c, 3, 3), 1, 1)
+    assert torch.equal(fused, K.gamma_beta_bwd_acc(dg, db, m, plain.clone()))
+
+
+@pytest.mark.parametrize('case', [
+    dict(n=4, ci=3, co=64, h=32, w=32), dict(n=4, ci=64, co=64, h=14, w=14), dict(n=4, ci=64, co=96, h=8, w=8),
+    dict(n=4, ci=64, co=64, h=8, w=8, k=1, pad=0), dict(n=4, ci=64, co=64, h=64, w=64, stride=2),
+    dict(n=4, ci=64, co=64, h=8, w=8, stride=3),
+    dict(n=3, ci=64, co=64, h=4, w=4)])
+def test_shapes_outside_the_kernel_are_refused_before_anything_is_enqueued(K, case):
+    from deepipr_amd import _lib
+    k, stride, pad = case.get('k', 3), case.get('stride', 1), case.get('pad', 1)
+    n, ci, co, h, w = case['n'], case['ci'], case['co'], case['h'], case['w']
+    assert K.conv_wgrad_workspace(n, ci, co, h, w, k, k, stride, pad) == 0
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x, dy = _rand((n, ci, h, w), 1), _rand((n, co, oh, ow), 2)
+    assert K.conv_wgrad(x, dy, (co, ci, k, k), stride, pad) is None
+    dw = torch.empty(co, ci, k, k, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = _lib.lib().deepipr_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, ci, co, h, w, k, k, stride, pad,
+                                       None, None, None, ws.data_ptr(), ws.numel(), None)
+    assert rc == -3 and b'conv_wgrad' in _lib.lib().deepipr_last_error()
+
+
+def test_convblock_and_passport_layer_take_the_kernel_and_match_the_library_gradient(K, monkeypatch):
+    """Module level: ConvBlock and PassportBlock (data convolution inside the fused node, rank-2 term fused) with the own
+    weight gradient against the same modules with DEEPIPR_OWN_WGRAD off (the vendor library's wgrad + the separate
+    rank-2 update): same forward bit for bit, weight gradients within 1e-5 of scale."""
+    from deepipr_amd import passport_ops as P
+    from deepipr_amd.models.layers.conv2d import ConvBlock
+    from deepipr_amd.models.layers.passportconv2d import PassportBlock
+    calls = {'n': 0}
+    real = type(K).conv_wgrad
+
+    def counted(self, *a, **k):
+        calls['n'] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(type(K), 'conv_wgrad', counted)
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(P, 'OWN_WGRAD', own)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        plain = ConvBlock(64, 64, 3, 1, 1).to(DEV)
+        pas = PassportBlock(64, 64, 3, 1, 1, {'norm_type': 'bn', 'key_type': 'random', 'sign_loss': 0.1}).to(DEV)
+        x = _rand((16, 64, 16, 16), 3).requires_grad_(True)
+        y = pas(plain(x))
+        (y.square().mean() + pas.sign_loss.loss).backward()
+        res[own] = (y.detach(), plain.conv.weight.grad, pas.weight.grad, x.grad)
+    assert calls['n'] == 2                                   # both layers of the `own` pass, none of the other
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
