@@ -39,6 +39,7 @@ from deepipr_amd.models.resnet_passport import ResNet18Passport                 
 from deepipr_amd.models.resnet_passport_private import ResNet18Private             # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32, = the vector rate)
 # algorithmic bytes per activation element are accounted by the library per timed
 # launch: single-pass norm+affine+ReLU 8 forward / 12 backward; 3-launch form: stats 4, apply 8, backward sums 8,
 # backward apply 12; plain affine 8 / 12; SGD 20 per parameter
@@ -136,8 +137,9 @@ def cpu_baseline(args, budget_s=20.0):
                                        imagenet=hw > 32)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(args.batch, 3, hw, hw, generator=g)
-    y = torch.randint(0, args.classes, (args.batch,), generator=g)
+    extra = 2 if args.scheme == 3 else 0                    # V3: the trigger pair rides along with every batch
+    x = torch.randn(args.batch + extra, 3, hw, hw, generator=g)
+    y = torch.randint(0, args.classes, (args.batch + extra,), generator=g)
     step = torch_ref.v1_step if args.scheme == 1 else torch_ref.v23_step
     model.train()
     step(model, opt, x, y)                                  # warm-up (oneDNN primitive creation)
@@ -249,9 +251,11 @@ def dry_run(args):
     dev = torch.device('cpu') if (args.backend == 'gloo' or not torch.cuda.is_available()) else torch.device('cuda', _local)
     dt = D.max_over_ranks(dt, dev)
     seen = dist.get_world_size() if dist.is_initialized() else 1
+    ranks = D.ranks_seen(dev)                               # counted by a collective (gloo here, RCCL on the GPUs)
     if rank == 0:
         print(json.dumps({'metric': 'dry run: launcher and process group only', 'value': None, 'unit': 'img/s',
-                          'n_gpus': args.gpus, 'world_size_seen': seen, 'steps': 0, 'warmup': 0, 'dry_run': True,
+                          'n_gpus': args.gpus, 'world_size_seen': seen, 'rccl_ranks_seen': ranks, 'steps': 0, 'warmup': 0,
+                          'scheme': args.scheme, 'dry_run': True,
                           'barrier_s': round(dt, 4)}), flush=True)
     D.shutdown()
 
@@ -262,7 +266,9 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
-    ap.add_argument('--scheme', type=int, default=1, choices=[1, 2])
+    ap.add_argument('--scheme', type=int, default=1, choices=[1, 2, 3],
+                    help='1 = V1 (train_v1.py), 2 = V2 private passports, 3 = V3: V2 + a trigger-set pair appended to every '
+                         'batch (train_v23.py --train-backdoor; experiments/trainer_private.py:135-146, dataset.py:188-191)')
     ap.add_argument('--classes', type=int, default=10)
     ap.add_argument('--arch', default='resnet18', choices=['resnet18', 'resnet50', 'alexnet'])
     ap.add_argument('--image-size', type=int, default=32, help='32 = CIFAR shapes, 224 = ImageNet shapes')
@@ -289,7 +295,7 @@ def main():
         return dry_run(args)
 
     def note(msg):
-        if args.verbose:
+        if args.verbose or args.gpus > 1:                  # several ranks: always say where the time goes (stderr)
             print('bench.py [%7.1f s] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     rank, local_rank, world = D.init_from_env(args.backend)
@@ -333,17 +339,54 @@ def main():
         wrap = lambda m: m
         from deepipr_amd.flat_sgd import FlatSGD
         opt = FlatSGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    # V3: the trigger-set loader hands out 2 images per step (dataset.py:188-191), concatenated to the batch INSIDE the
+    # step as the reference does (trainer_private.py:142-146): 2 small kernels per step, part of the timed region
+    wm = None
+    if args.scheme == 3:
+        wm = ([torch.randn(2, 3, hw, hw, generator=g).to(device) for _ in range(nb)],
+              [torch.randint(0, args.classes, (2,), generator=g).to(device) for _ in range(nb)])
+
+    def batch(i):
+        if wm is None:
+            return xs[i % nb], ys[i % nb]
+        return torch.cat([xs[i % nb], wm[0][i % nb]], dim=0), torch.cat([ys[i % nb], wm[1][i % nb]], dim=0)
     if args.scheme == 1:
         net = wrap(model)
-        step = lambda i: train_step_v1(net, opt, xs[i % nb], ys[i % nb])
+        step = lambda i: train_step_v1(net, opt, *batch(i))
     else:
         net = wrap(DualBranch(model))
-        step = lambda i: train_step_v23(net, opt, xs[i % nb], ys[i % nb])
+        step = lambda i: train_step_v23(net, opt, *batch(i))
 
     note('keys drawn, state broadcast, optimiser built')
-    all_elems, elems = fused_layer_elements(model, lambda: step(0))   # per step: every fused-kernel layer call
-    torch.cuda.synchronize()
-    note('first eager step done (MIOpen find / kernel selection for every conv shape)')
+    # Find phase: one collective-free forward + backward (torch.autograd.grad: no gradient hooks, no optimiser) so that
+    # MIOpen picks its solver for every convolution shape -- RANK 0 FIRST, the others behind a barrier: they then find
+    # rank 0's records in the user find-database, take the same solvers and skip the measurement (distributed.rank0_first).
+    # Every rank runs it on rank 0's batch from the broadcast weights, so the ranks' gradients must agree: bit for bit when
+    # they run the same deterministic kernels, to rounding otherwise -- all-gathered and reported (ranks_agree*).
+    import torch.distributed as tdist
+    many = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    raw = model if args.scheme == 1 else DualBranch(model)
+    fwd_loss = (train_step_v1 if args.scheme == 1 else train_step_v23).forward_loss
+    probe_x, probe_y = batch(0)
+    if many:
+        probe_x, probe_y = probe_x.clone(), probe_y.clone()
+        tdist.broadcast(probe_x, 0)
+        tdist.broadcast(probe_y, 0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    probe = {}
+
+    def find_pass():
+        objective, _ = fwd_loss(raw, probe_x, probe_y)
+        probe['grads'] = torch.autograd.grad(objective, params, allow_unused=True)
+    keep0 = {k: v.clone() for k, v in model.state_dict().items()} if many else None
+    (all_elems, elems), find_s = D.rank0_first(lambda: fused_layer_elements(model, find_pass), device)
+    agree, agree_tol = D.gradients_agree(probe.pop('grads'), device)
+    if keep0 is not None:                                  # every rank back on the broadcast state (norm statistics moved)
+        with torch.no_grad():
+            model.load_state_dict(keep0)
+    del probe_x, probe_y, keep0
+    note('find phase done in %.1f s (rank 0 first): MIOpen solver selection for every conv shape; ranks agree: %s'
+         % (find_s, agree))
     # Launch mode of the timed region: hipGraph replay by default.  The step issues ~260 dispatches (~500 for the
     # dual-forward V2/V3 step); eager enqueue costs 4.5-9 ms of host time against 5.1-5.6 ms of GPU time, so an eager
     # step is host-bound exactly where it matters most (32 images per GPU in config P).
@@ -356,7 +399,6 @@ def main():
     # --eager: eager dispatch with the exchange overlapped with backward; --ddp: DistributedDataParallel (eager).
     eager_step = step
     use_graph = not args.eager and not args.ddp
-    import torch.distributed as tdist
     fn = train_step_v1 if args.scheme == 1 else train_step_v23
     graphed, launch_form = None, 'eager'
 
@@ -373,9 +415,9 @@ def main():
             # data parallel: backward cut into stages at the gradient buckets' boundaries, captured back to back;
             # bucket k's RCCL all-reduce on a side stream while stage k + 1 replays (experiments/staged.py)
             from deepipr_amd.experiments.staged import StagedStep
-            return StagedStep(fn, net, opt, xs[0], ys[0], graph=True)
+            return StagedStep(fn, net, opt, *batch(0), graph=True)
         from deepipr_amd.experiments.graph_step import GraphedTrainStep
-        return GraphedTrainStep(fn, net, opt, xs[0], ys[0], optimizer_in_graph=not tdist.is_initialized())
+        return GraphedTrainStep(fn, net, opt, *batch(0), optimizer_in_graph=not tdist.is_initialized())
 
     # (launch form, in-launch exchange allowed): with several ranks the forms are tried in this order until one runs
     # clean on EVERY rank; the last resort gives up the split-channel single-pass kernels (three launches for layers with
@@ -400,7 +442,7 @@ def main():
             if not sync_ok and _k.sync_user:
                 _k.set_user_sync(False)
             graphed = build(form)
-            step = lambda i, g=graphed: g(xs[i % nb], ys[i % nb])
+            step = lambda i, g=graphed: g(*batch(i))
             if len(forms) > 1:
                 # a few replays before the form is accepted: an in-launch exchange that timed out next to a collective
                 # (never seen with one process per GPU; staged.py explains why it should not happen) shows here
@@ -457,6 +499,7 @@ def main():
     dt = time.perf_counter() - t0
     note('timed region done: %.3f ms per step' % (1000.0 * dt / args.steps))
     sampled = len(range(0, args.steps, stride))
+    _k.profile_passport = timing                           # passport-layer launches also go to the scoped counters
     if timing and use_graph:
         sampled = min(args.steps, 30)
         for i in range(3):
@@ -469,9 +512,12 @@ def main():
         _lib.profile_enable(0)
     prof = _lib.profile_read() if timing else {}
     prof_bytes = _lib.profile_read_bytes() if timing else {}
+    prof_scope = _lib.profile_read_scope() if timing else {}
+    _k.profile_passport = False
     if timing:
         _lib.profile_enable(False)
     dt = D.max_over_ranks(dt, device)
+    ranks_seen = D.ranks_seen(device)                      # a SUM all-reduce of ones over the process group (1 without)
     # exposed part of the gradient exchange (staged mode): GPU time between the end of the last backward stage and the
     # SGD kernel -- pack + all-reduce of the buckets that could not travel under backward + the waits -- from events on
     # 20 extra steps after the timed region (max over ranks).  None when no exchange runs.
@@ -498,7 +544,6 @@ def main():
         D.shutdown()
         return
     value = args.gpus * args.batch * args.steps / dt
-    fwd_per_step = 1 if args.scheme == 1 else 2
     out = {
         'metric': 'images/sec %s-passport %s train step' % (
             {'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
@@ -511,11 +556,15 @@ def main():
         # bounded in-kernel waits of the single-pass kernels' partial-sum exchange that ever expired (must be 0)
         'exchange_timeouts': _exchange_timeouts(),
         'world_size_seen': (_td.get_world_size() if tdist_on else 1),
+        'rccl_ranks_seen': ranks_seen,                     # measured by a collective, not read from the environment
+        # after the find phase every rank ran the same forward + backward (rank 0's batch, broadcast weights): identical
+        # gradients bit for bit / within 1e-5 of scale (None on one GPU)
+        'ranks_agree_bitwise': agree, 'ranks_agree_1e-5': agree_tol, 'find_phase_s': round(find_s, 1),
         'exchange_us_exposed': None if exposed_us is None else round(exposed_us, 1),
         'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '
                                 '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %
                                 ({'resnet18': 'ResNet18', 'resnet50': 'ResNet50', 'alexnet': 'AlexNet'}[args.arch],
-                                 '1' if args.scheme == 1 else '2 private', args.arch, len(elems), args.classes,
+                                 {1: '1', 2: '2 private', 3: '3 private + trigger pair (2 extra images per step, not counted in img/s)'}[args.scheme], args.arch, len(elems), args.classes,
                                  args.image_size, args.image_size, args.batch)) + (
                                     '' if args.norm_type == 'bn' else ', norm_type ' + args.norm_type) + (
                                     ', library norm kernels (--no-fuse)' if args.no_fuse else ''),
@@ -545,6 +594,7 @@ def main():
                  'gamma_beta_fwd': 'passport GEMV, all passport layers in one launch: gamma, beta = W . pooled keys (4 B/weight)',
                  'gamma_beta_bwd': 'passport rank-2 update accumulated into the conv wgrad (8 B/weight)'}
     NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd')
+    hbm = None
     if out['exchange_timeouts']:
         out['roofline_refused'] = ('an in-launch exchange of the single-pass kernels timed out (%d buffer(s)): their '
                                    'outputs were poisoned; no roofline is reported for this run' % out['exchange_timeouts'])
@@ -568,25 +618,74 @@ def main():
             if n:
                 kern[name] = {'launches_per_step': round(n / sampled, 1), 'avg_us': round(1000.0 * ms / n, 3),
                               'us_per_step': round(1000.0 * ms / sampled, 1)}
-        # dominant kernel = the passport/norm streaming kernel with the most time per step
+        # HBM side: the passport / norm streaming kernel with the most time per step
         dom = max((k for k in kern if k in STREAMING and k not in NOT_DOMINANT), key=lambda k: kern[k]['us_per_step'])
         a = kern[dom]
         per_launch = a['bytes_per_step'] / max(1.0, a['launches_per_step'])
         # PMC traffic: rocprofv3 --pmc passes over this very command (tools/gpu_pmc_in_situ.sh, summarised into
         # profiles/pmc_traffic.json: in_situ_per_launch), quoted when that record describes this launch mix
         pmc_bytes = pmc_traffic('k_' + dom, 'in_situ_per_launch', per_launch)
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
-                           'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
-                           'traffic': pmc_bytes,
-                           # PMC counters need their own rocprofv3 passes: the figure is the committed record of such
-                           # passes over this command, quoted only when this run's launch mix equals the recorded one
-                           'traffic_source': 'profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' if pmc_bytes else None,
-                           'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
-                           'launches_per_step': a['launches_per_step'],
-                           'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '
-                                   'layer calls of %.1f MB among them); bytes and time summed over the timed '
-                                   'launches' % (len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
-                                                 len(elems), 4 * float(np.mean(elems)) / 1e6)}
+        hbm = {'bound': 'hbm', 'kernel': 'k_%s (%s)' % (dom, STREAMING[dom]),
+               'achieved': a['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a['frac'],
+               'traffic': pmc_bytes,
+               # PMC counters need their own rocprofv3 passes: the figure is the committed record of such
+               # passes over this command, quoted only when this run's launch mix equals the recorded one
+               'traffic_source': 'profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' if pmc_bytes else None,
+               'bytes_per_launch': int(per_launch), 'avg_us': a['avg_us'],
+               'launches_per_step': a['launches_per_step'],
+               'note': '%d fused norm layer calls per step over activations of %.1f-%.1f MB (%d passport '
+                       'layer calls of %.1f MB among them); bytes and time summed over the timed '
+                       'launches' % (len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
+                                     len(elems), 4 * float(np.mean(elems)) / 1e6)}
+        # MFMA side: the weight-gradient kernel of the data convolutions (its profile slot accounts FLOPs)
+        ms, n = prof.get('conv_wgrad', (0.0, 0))
+        mfma = None
+        if n:
+            flops = prof_bytes.get('conv_wgrad', 0.0)
+            rms, rn = prof.get('conv_wgrad_reduce', (0.0, 0))
+            tf = flops / (ms * 1e-3) / 1e12
+            mfma = {'bound': 'mfma', 'kernel': 'k_conv3x3_wgrad (weight gradient of the 3x3 data convolutions, stride 1 / 2, on '
+                    'v_mfma_f32_32x32x2_f32; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)',
+                    'achieved': round(tf, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'flops_per_launch': int(flops / n), 'avg_us': round(1000.0 * ms / n, 2),
+                    'launches_per_step': round(n / sampled, 1), 'us_per_step': round(1000.0 * ms / sampled, 1),
+                    'reduce_us_per_step': round(1000.0 * rms / sampled, 1),
+                    'achieved_incl_reduce': round(flops / ((ms + rms) * 1e-3) / 1e12, 1),
+                    'note': 'algorithmic FLOPs = 2 * Co * Ci * 9 * N * OH * OW per launch (SURVEY.md 8(d)), summed over '
+                            'the timed launches / their summed kernel time'}
+        # `roofline` = the dominant hand-written kernel of the step by time; both sides are always reported
+        if mfma is not None and mfma['us_per_step'] >= a['us_per_step']:
+            out['roofline'], out['roofline_hbm'] = mfma, hbm
+        else:
+            out['roofline'] = hbm
+            if mfma is not None:
+                out['roofline_mfma'] = mfma
+        # the passport-affine kernels ON THEIR OWN (north star: ">= 60 % HBM roofline on the passport-affine kernel"): only
+        # the launches that serve passport layers -- norm + passport affine + ReLU (+ sign loss, + folded residual tail),
+        # 8 B / element forward, 12 (20 - 24 with a tail) backward
+        ps = {}
+        for name in ('bn_res_fwd', 'bn_res_bwd', 'bn_affine_fwd', 'bn_affine_bwd', 'bn_stats', 'bn_bwd_reduce', 'gn_fwd',
+                     'gn_bwd', 'affine_fwd', 'affine_bwd'):
+            pms, pn, pb = prof_scope.get(name, (0.0, 0, 0.0))
+            if pn:
+                ps[name] = {'launches_per_step': round(pn / sampled, 1), 'avg_us': round(1000.0 * pms / pn, 3),
+                            'us_per_step': round(1000.0 * pms / sampled, 1), 'bytes_per_launch': int(pb / pn),
+                            'GBps': round(pb / (pms * 1e-3) / 1e9, 1)}
+        if ps:
+            tot_ms = sum(prof_scope[k][0] for k in ps)
+            tot_b = sum(prof_scope[k][2] for k in ps)
+            gbps = tot_b / (tot_ms * 1e-3) / 1e9
+            out['roofline_passport'] = {
+                'bound': 'hbm', 'kernel': 'the norm + passport affine + ReLU launches of the %d passport layer calls only '
+                '(forward and backward together)' % len(elems),
+                'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBS, 4),
+                'traffic': None, 'us_per_step': round(1000.0 * tot_ms / sampled, 1),
+                'activation_MB': round(4 * float(np.mean(elems)) / 1e6, 2), 'kernels': ps,
+                'note': 'latency-bound: %.1f MB activations, a launch moves %.0f-%.0f MB in %.1f-%.1f us'
+                        % (4 * float(np.mean(elems)) / 1e6, min(v['bytes_per_launch'] for v in ps.values()) / 1e6,
+                           max(v['bytes_per_launch'] for v in ps.values()) / 1e6,
+                           min(v['avg_us'] for v in ps.values()), max(v['avg_us'] for v in ps.values()))}
         out['kernels'] = kern
         if args.gpus == 1 and not args.no_stress:
             out['roofline_stress'] = stress_roofline(device)

@@ -88,6 +88,9 @@ SIGNATURES = {
                                        _vp]),
     'deepipr_set_resident': (_int, [_int]),
     'deepipr_profile_read_bytes': (_int, [_int, _c.POINTER(_c.c_double)]),
+    'deepipr_profile_scope': (_int, [_int]),
+    'deepipr_profile_read_scope': (_int, [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong),
+                                          _c.POINTER(_c.c_double)]),
     'deepipr_conv_wgrad_workspace_bytes': (_sz, [_int] * 9),
     'deepipr_conv_wgrad': (_int, [_f32p, _f32p, _f32p] + [_int] * 9 + [_f32p, _f32p, _f64p, _vp, _sz, _vp]),
 }
@@ -222,6 +225,21 @@ def profile_read():
         ms, n = ctypes.c_double(), ctypes.c_longlong()
         check(lib().deepipr_profile_read(i, ctypes.byref(ms), ctypes.byref(n)), 'profile_read')
         out[name] = (ms.value, n.value)
+    return out
+
+
+def profile_scope(on):
+    """Open / close the scope whose launches are also accounted apart (profile_read_scope)."""
+    check(lib().deepipr_profile_scope(int(bool(on))), 'profile_scope')
+
+
+def profile_read_scope():
+    """{kernel name: (total_ms, launches, algorithmic bytes)} of the launches issued inside a profile scope."""
+    out = {}
+    for i, name in enumerate(PROFILE_KERNELS):
+        ms, n, b = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        check(lib().deepipr_profile_read_scope(i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)), 'profile_read_scope')
+        out[name] = (ms.value, n.value, b.value)
     return out
 
 

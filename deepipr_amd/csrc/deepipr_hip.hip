@@ -77,11 +77,17 @@ struct ProfState {
     std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> pool;
-    struct Pending { int k; hipEvent_t a, b; double bytes; };
+    struct Pending { int k; hipEvent_t a, b; double bytes; int scope; };
     std::vector<Pending> pending;
     double total_ms[DEEPIPR_PROFILE_KERNELS] = {};
     long long launches[DEEPIPR_PROFILE_KERNELS] = {};
     double total_bytes[DEEPIPR_PROFILE_KERNELS] = {};   // algorithmic bytes of the timed launches
+    // the same three, of the launches issued while a caller-declared scope was open (deepipr_profile_scope: the
+    // passport layers of a net, so that their kernels can be reported apart from the plain norm layers')
+    int scope = 0;
+    double scope_ms[DEEPIPR_PROFILE_KERNELS] = {};
+    long long scope_launches[DEEPIPR_PROFILE_KERNELS] = {};
+    double scope_bytes[DEEPIPR_PROFILE_KERNELS] = {};
 };
 ProfState g_prof;
 
@@ -106,7 +112,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!a) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (used) g_prof.pending.push_back({k, a, b, bytes});
+        if (used) g_prof.pending.push_back({k, a, b, bytes, g_prof.scope});
         else { g_prof.pool.push_back(a); g_prof.pool.push_back(b); }
     }
 };
@@ -2908,7 +2914,10 @@ int deepipr_stream_wait_event(void *stream, void *event) {
 int deepipr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (on == 1) {                                   // 1 = start afresh, 2 = resume, 0 = pause
-        for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) { g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; g_prof.total_bytes[i] = 0.0; }
+        for (int i = 0; i < DEEPIPR_PROFILE_KERNELS; ++i) {
+            g_prof.total_ms[i] = 0.0; g_prof.launches[i] = 0; g_prof.total_bytes[i] = 0.0;
+            g_prof.scope_ms[i] = 0.0; g_prof.scope_launches[i] = 0; g_prof.scope_bytes[i] = 0.0;
+        }
     }
     g_prof.on = on != 0;
     return DEEPIPR_OK;
@@ -2922,6 +2931,11 @@ void prof_drain_locked() {                         // everything recorded so far
             g_prof.total_ms[p.k] += ms;
             g_prof.launches[p.k] += 1;
             g_prof.total_bytes[p.k] += p.bytes;
+            if (p.scope) {
+                g_prof.scope_ms[p.k] += ms;
+                g_prof.scope_launches[p.k] += 1;
+                g_prof.scope_bytes[p.k] += p.bytes;
+            }
         }
         g_prof.pool.push_back(p.a);
         g_prof.pool.push_back(p.b);
@@ -2937,6 +2951,23 @@ int deepipr_profile_read(int kernel, double *total_ms, long long *launches) {
     prof_drain_locked();
     *total_ms = g_prof.total_ms[kernel];
     *launches = g_prof.launches[kernel];
+    return DEEPIPR_OK;
+}
+
+int deepipr_profile_scope(int scope) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.scope = scope != 0;
+    return DEEPIPR_OK;
+}
+
+int deepipr_profile_read_scope(int kernel, double *total_ms, long long *launches, double *total_bytes) {
+    if (kernel < 0 || kernel >= DEEPIPR_PROFILE_KERNELS || !total_ms || !launches || !total_bytes)
+        return fail(DEEPIPR_EINVAL, "profile_read_scope: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain_locked();
+    *total_ms = g_prof.scope_ms[kernel];
+    *launches = g_prof.scope_launches[kernel];
+    *total_bytes = g_prof.scope_bytes[kernel];
     return DEEPIPR_OK;
 }
 

@@ -107,3 +107,69 @@ def barrier():
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def ranks_seen(device):
+    """How many ranks a collective actually reaches: the SUM all-reduce of a one per rank (1 without a process group).
+    bench.py reports it next to WORLD_SIZE, which only says what the launcher promised."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def rank0_first(fn, device=None):
+    """Run `fn` on rank 0, then -- behind a barrier -- on every other rank.
+
+    The first convolution of every shape runs MIOpen's find step (cudnn.benchmark, train_v1.py:8), which measures the
+    candidate solvers and records the winner in the per-user find database on disk.  N ranks started together race on
+    that file and, worse, may each measure a different winner: the ranks of one job would then run different kernels
+    (weak-scaling time is the slowest rank's; run-to-run bits differ between ranks).  With rank 0 first, its records are
+    on disk when the others look: they take the same solvers and skip the measurement.  -> (fn's result, seconds the
+    find phase took on this rank)."""
+    import time
+    t0 = time.perf_counter()
+    many = dist.is_initialized() and dist.get_world_size() > 1
+    res = None
+    if not many or dist.get_rank() == 0:
+        res = fn()
+        if device is not None and torch.device(device).type == 'cuda':
+            torch.cuda.synchronize(device)
+    if many:
+        barrier()
+        if dist.get_rank() != 0:
+            res = fn()
+            if device is not None and torch.device(device).type == 'cuda':
+                torch.cuda.synchronize(device)
+        barrier()
+    return res, time.perf_counter() - t0
+
+
+def gradients_agree(grads, device):
+    """After every rank ran the SAME forward + backward (same weights, same batch): do all ranks hold the same gradients?
+    -> (bit for bit, within 1e-5 of scale); (None, None) without a process group.  Bit-identical gradients mean the ranks
+    ran the same, deterministic kernels (the vendor library's solver choice included); two small all-gathers."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return None, None
+    bits = torch.zeros((), dtype=torch.int64, device=device)
+    sums = []
+    for g in grads:
+        if g is None:
+            continue
+        g = g.detach().contiguous()
+        bits = bits + g.view(torch.int32).to(torch.int64).sum()
+        sums.append(torch.stack([g.double().sum(), g.double().abs().sum()]))
+    vec = torch.cat([bits.to(torch.float64).reshape(1)] + sums) if sums else bits.to(torch.float64).reshape(1)
+    world = dist.get_world_size()
+    gathered = [torch.zeros_like(vec) for _ in range(world)]
+    dist.all_gather(gathered, vec)
+    allb = [torch.zeros_like(bits) for _ in range(world)]
+    dist.all_gather(allb, bits)
+    bitwise = all(int(b.item()) == int(allb[0].item()) for b in allb)
+    ref = gathered[0][1:].view(-1, 2)
+    close = True
+    for g in gathered[1:]:
+        d = (g[1:].view(-1, 2)[:, 0] - ref[:, 0]).abs()
+        close = close and bool((d <= 1e-5 * ref[:, 1] + 1e-30).all())
+    return bool(bitwise), bool(close)

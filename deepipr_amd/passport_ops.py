@@ -254,6 +254,9 @@ class HipKernels:
     # round-trips per layer call on the host.
     _arena = {}
 
+    # bench.py sets this while it times kernels: the calls that serve PASSPORT layers open the library's profile scope
+    profile_passport = False
+
     _ws_bytes = {}
 
     def _bn_ws_bytes(self, n, c, hw):
@@ -471,6 +474,9 @@ class HipKernels:
         sync = self._sync_words(dev, st) if training else None
         if sync is not None and self.bn_slices(n, c, hw) > 1:
             self.sync_launches += 1
+        scoped = self.profile_passport and (b is not None or pre or weight is not None)
+        if scoped:
+            _lib.profile_scope(True)
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_fwd(
                 x.data_ptr(), _p(weight), _p(m), _p(gamma_in), _p(beta_in), _p(b), alpha, margin, l2,
@@ -478,6 +484,8 @@ class HipKernels:
                 y.data_ptr(), base, p_gamma if weight is not None else None, p_beta if weight is not None else None,
                 p_loss if b is not None else None, (p_loss + 4) if b is not None else None, _p(bits), _p(residual),
                 ws, sync, st), 'passport_bn_fwd')
+        if scoped:
+            _lib.profile_scope(False)
         table = small[:8 * c].view(c, 8)
         gamma = beta = loss = acc = None
         if weight is not None:
@@ -507,6 +515,9 @@ class HipKernels:
         sync = self._sync_words(dev, st)
         if sync is not None and self.bn_slices(n, c, hw) > 1:
             self.sync_launches += 1
+        scoped = self.profile_passport and (m is not None or b is not None)
+        if scoped:
+            _lib.profile_scope(True)
         with _on(dev):
             _lib.check(lib.deepipr_passport_bn_bwd(
                 dy.data_ptr(), x.data_ptr(), table.data_ptr(), _p(m), _p(b), alpha, margin, l2, _p(dloss),
@@ -514,6 +525,8 @@ class HipKernels:
                 (dw.numel() // c) if dw is not None else 0, int(relu), dx.data_ptr(), _p(dw), pg, pg + 4 * c,
                 scratch + nws, scratch, sync, _p(dy2), _p(tail_out), _p(dres), st),
                 'passport_bn_bwd')
+        if scoped:
+            _lib.profile_scope(False)
         if tail_out is not None:
             return dx, dw, dgb[0], dgb[1], dres
         return dx, dw, dgb[0], dgb[1]

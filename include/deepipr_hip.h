@@ -86,6 +86,11 @@ int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resu
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
 int deepipr_profile_read_bytes(int kernel, double *total_bytes);
+/* Launches issued between deepipr_profile_scope(1) and deepipr_profile_scope(0) are ALSO accounted in a second set of
+ * counters (the host opens the scope around the calls that serve passport layers, so that bench.py can report the
+ * passport-affine kernels apart from the plain norm layers that share them: `roofline_passport`). */
+int deepipr_profile_scope(int scope);
+int deepipr_profile_read_scope(int kernel, double *total_ms, long long *launches, double *total_bytes);
 
 /* ------------------------------------------------------------------ passport conv -> global pool
  * m[k] = mean over (b, oh, ow) of im2col(key)[b, k, (oh,ow)], k = (ci*kh + r)*kw + q, kept in f64,

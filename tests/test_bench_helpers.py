@@ -44,13 +44,14 @@ def test_bench_self_launches_n_ranks_when_typed_without_a_launcher():
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--backend', 'gloo'],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--scheme', '3', '--dry-run', '--backend', 'gloo'],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['dry_run'] is True and rec['value'] is None
+    assert rec['rccl_ranks_seen'] == 2                       # counted by an all-reduce of ones, not read from the environment
 
 
 def test_self_launcher_takes_its_ranks_down_with_it(tmp_path):

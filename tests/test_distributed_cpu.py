@@ -230,3 +230,55 @@ def test_entry_points_with_two_ranks(private, ddp, tmp_path):
     for k, v in r0['state'].items():
         assert torch.equal(v, r1['state'][k]), k
         assert torch.equal(v, saved[k]), k
+
+
+def _find_phase_worker(rank, world, port, out_dir):
+    """rank0_first / gradients_agree / ranks_seen, the helpers bench.py's find phase is made of (two gloo ranks)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import time
+    from deepipr_amd import distributed as D
+    D.init_from_env('gloo')
+    dev = torch.device('cpu')
+    stamp = os.path.join(out_dir, 'rank0_done')
+
+    def first_convolutions():
+        if rank == 0:
+            time.sleep(0.5)                                  # rank 0's "find" takes a while ...
+            open(stamp, 'w').write('db')
+            return 'measured'
+        return 'from the database' if os.path.exists(stamp) else 'raced'      # ... the others must come after it
+    res, seconds = D.rank0_first(first_convolutions, dev)
+    seen = D.ranks_seen(dev)
+    same = [torch.arange(6.0).view(2, 3), None, torch.ones(4)]
+    agree_same = D.gradients_agree(same, dev)
+    diff = [torch.arange(6.0).view(2, 3) + (1e-3 if rank else 0.0), None, torch.ones(4)]
+    agree_diff = D.gradients_agree(diff, dev)
+    near = [torch.arange(1.0, 7.0).view(2, 3) * (1.0 + (1e-7 if rank else 0.0)), torch.ones(4)]
+    agree_near = D.gradients_agree(near, dev)
+    torch.save(dict(res=res, seconds=seconds, seen=seen, agree_same=agree_same, agree_diff=agree_diff,
+                    agree_near=agree_near), os.path.join(out_dir, 'r%d.pt' % rank))
+    D.shutdown()
+
+
+def test_find_phase_helpers_rank0_first_then_the_others(tmp_path):
+    """bench.py's find phase for N > 1: rank 0 runs the first convolutions alone, the others behind a
+    barrier (they then read rank 0's MIOpen find records instead of racing on the user database); a SUM all-reduce of ones
+    counts the ranks a collective really reaches; the ranks' gradients of the same step are compared bit for bit and to
+    1e-5 of scale."""
+    mp.spawn(_find_phase_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in (0, 1))
+    assert r0['res'] == 'measured' and r1['res'] == 'from the database'
+    assert r0['seen'] == r1['seen'] == 2
+    assert r0['agree_same'] == r1['agree_same'] == (True, True)
+    assert r0['agree_diff'] == r1['agree_diff'] == (False, False)
+    assert r0['agree_near'] == r1['agree_near'] == (False, True)          # not the same bits, the same to rounding
+    assert r1['seconds'] >= 0.4                                           # rank 1 waited for rank 0
+
+
+def test_find_phase_helpers_without_a_process_group():
+    from deepipr_amd import distributed as D
+    res, _s = D.rank0_first(lambda: 7)
+    assert res == 7 and D.ranks_seen(torch.device('cpu')) == 1
+    assert D.gradients_agree([torch.ones(2)], torch.device('cpu')) == (None, None)
