@@ -4067,6 +4067,7 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
 // =============================================================================================
 namespace {
 #include "deepipr_conv.inc"
+#include "deepipr_conv_fwd.inc"
 
 template <class C>
 void launch_wgrad(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
@@ -4125,6 +4126,104 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     else DEEPIPR_WGRAD_REDUCE(1, tiles * 36, 256);
 #undef DEEPIPR_WGRAD_REDUCE
     return check_launch("conv_wgrad");
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// data convolution: forward and backward-data on the fp32 matrix cores (deepipr_conv_fwd.inc)
+// =============================================================================================
+namespace {
+template <class C, bool DGRAD>
+void launch_gemm(ProfScope &prof, const FwPlan &p, const float *wgt, const float *in, float *out, int Cin, int M, int H,
+                 hipStream_t st) {
+    DEEPIPR_LAUNCH(prof, (k_conv_gemm<C, DGRAD>), dim3(p.grid), dim3(256), st, wgt, in, out, Cin, M, H, p.bands);
+}
+
+template <bool DGRAD>
+int conv_gemm(int slot, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, int W, int k, int stride,
+              int pad, hipStream_t st, const char *what) {
+    const FwPlan p = plan_conv_gemm(N, Cin, M, H, W, k, stride, pad);
+    if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "%s: shape outside the kernel (use the library's convolution)", what);
+    if (!aligned16(wgt) || !aligned16(in) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
+    ProfScope prof(slot, st);
+    prof.bytes = 2.0 * M * Cin * k * k * static_cast<double>(N) * (H / stride) * (W / stride);       // FLOPs
+    switch (p.cfg) {
+        case 11: launch_gemm<FwCfg<1, 9, 32, 8, 1, 4, 1, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 21: launch_gemm<FwCfg<1, 9, 32, 2, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 31: launch_gemm<FwCfg<1, 9, 16, 8, 1, 2, 2, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 41: launch_gemm<FwCfg<1, 9, 16, 4, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 51: launch_gemm<FwCfg<1, 9, 8, 8, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 61: launch_gemm<FwCfg<1, 9, 4, 4, 4, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        default:
+            if (DGRAD) return fail(DEEPIPR_EUNSUPPORTED, "%s: backward-data of a stride-2 convolution is not a gather", what);
+            switch (p.cfg) {
+                case 42: launch_gemm<FwCfg<2, 9, 16, 4, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 52: launch_gemm<FwCfg<2, 9, 8, 8, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 62: launch_gemm<FwCfg<2, 9, 4, 4, 4, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 142: launch_gemm<FwCfg<2, 1, 16, 4, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 152: launch_gemm<FwCfg<2, 1, 8, 8, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 162: launch_gemm<FwCfg<2, 1, 4, 4, 4, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
+            }
+    }
+    return check_launch(what);
+}
+
+template <class C>
+void launch_dgrad_s2(ProfScope &prof, const FwPlan &p, const float *wgt, const float *dy, float *dx, int Co, int Ci, int oh,
+                     hipStream_t st) {
+    DEEPIPR_LAUNCH(prof, (k_conv_dgrad_s2<C>), dim3(p.grid), dim3(256), st, wgt, dy, dx, Co, Ci, oh, p.bands);
+}
+
+int conv_dgrad_s2(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int pad, hipStream_t st) {
+    if (H % 2 || W % 2) return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: odd map");
+    const int oh = H / 2, ow = W / 2;
+    const FwPlan p = plan_conv_dgrad_s2(N, Co, Ci, oh, ow, k, pad);
+    if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: shape outside the kernel (use the library's backward-data)");
+    if (!aligned16(w) || !aligned16(dy) || !aligned16(dx)) return fail(DEEPIPR_EINVAL, "conv_dgrad: pointers must be 16-byte aligned");
+    ProfScope prof(DEEPIPR_K_CONV_DGRAD, st);
+    prof.bytes = 2.0 * Ci * Co * k * k * static_cast<double>(N) * oh * ow;       // FLOPs
+    switch (p.cfg) {
+        case 11: launch_dgrad_s2<FwCfg<1, 9, 32, 8, 1, 4, 1, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 21: launch_dgrad_s2<FwCfg<1, 9, 32, 2, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 31: launch_dgrad_s2<FwCfg<1, 9, 16, 8, 1, 2, 2, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 41: launch_dgrad_s2<FwCfg<1, 9, 16, 4, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 51: launch_dgrad_s2<FwCfg<1, 9, 8, 8, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 61: launch_dgrad_s2<FwCfg<1, 9, 4, 4, 4, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 141: launch_dgrad_s2<FwCfg<1, 1, 16, 4, 1, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 151: launch_dgrad_s2<FwCfg<1, 1, 8, 8, 1, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        case 161: launch_dgrad_s2<FwCfg<1, 1, 4, 4, 4, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+        default: return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: no instance");
+    }
+    return check_launch("conv_dgrad");
+}
+}  // namespace
+
+extern "C" {
+
+int deepipr_conv_supported(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction) {
+    if (direction == 0) return plan_conv_gemm(N, Ci, Co, H, W, k, stride, pad).cfg ? 1 : 0;
+    if (direction != 1) return 0;
+    if (stride == 1) return plan_conv_gemm(N, Co, Ci, H, W, k, stride, pad).cfg ? 1 : 0;
+    if (stride == 2 && H % 2 == 0 && W % 2 == 0) return plan_conv_dgrad_s2(N, Co, Ci, H / 2, W / 2, k, pad).cfg ? 1 : 0;
+    return 0;
+}
+
+int deepipr_conv_fwd(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
+                     void *stream) {
+    if (!x || !w || !y) return fail(DEEPIPR_EINVAL, "conv_fwd: null pointer");
+    return conv_gemm<false>(DEEPIPR_K_CONV_FWD, w, x, y, N, Ci, Co, H, W, k, stride, pad, static_cast<hipStream_t>(stream),
+                            "conv_fwd");
+}
+
+int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
+                       int pad, void *stream) {
+    if (!dy || !w || !dx) return fail(DEEPIPR_EINVAL, "conv_dgrad: null pointer");
+    if (stride == 2) return conv_dgrad_s2(dy, w, dx, N, Ci, Co, H, W, k, pad, static_cast<hipStream_t>(stream));
+    if (stride != 1) return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: stride 1 or 2 (use the library's backward-data)");
+    return conv_gemm<true>(DEEPIPR_K_CONV_DGRAD, w, dy, dx, N, Co, Ci, H, W, k, stride, pad, static_cast<hipStream_t>(stream),
+                           "conv_dgrad");
 }
 
 }  // extern "C"

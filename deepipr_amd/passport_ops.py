@@ -676,6 +676,43 @@ class HipKernels:
                        'conv_wgrad')
         return dw
 
+    # ---- data convolution: forward / backward-data on the fp32 matrix cores (deepipr_conv_fwd / _dgrad) ----
+    _conv_ok = {}
+
+    def conv_supported(self, n, ci, co, h, w, k, stride, pad, direction):
+        """direction 0 = forward, 1 = backward-data; h, w: the convolution's input map."""
+        key = (n, ci, co, h, w, k, stride, pad, direction)
+        v = self._conv_ok.get(key)
+        if v is None:
+            v = self._conv_ok[key] = bool(_lib.lib().deepipr_conv_supported(*key))
+        return v
+
+    def conv_fwd(self, x, weight, stride, pad):
+        """conv2d(x, weight) (no bias, square kernel / stride / padding), or None when the shape is outside the kernel."""
+        n, ci, h, w = x.shape
+        co, _ci, k, _k = weight.shape
+        if _ci != ci or _k != k or not self.conv_supported(n, ci, co, h, w, k, stride, pad, 0):
+            return None
+        dev = _chk(x, weight)
+        y = torch.empty((n, co, h // stride, w // stride), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_conv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), n, ci, co, h, w, k, stride,
+                                                  pad, _stream(dev)), 'conv_fwd')
+        return y
+
+    def conv_dgrad(self, dy, weight, x_shape, stride, pad):
+        """Gradient of conv2d(x, weight) with respect to x, or None when the shape is outside the kernel."""
+        n, ci, h, w = x_shape
+        co, _ci, k, _k = weight.shape
+        if _ci != ci or _k != k or not self.conv_supported(n, ci, co, h, w, k, stride, pad, 1):
+            return None
+        dev = _chk(dy, weight)
+        dx = torch.empty((n, ci, h, w), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_conv_dgrad(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, ci, co, h, w, k,
+                                                    stride, pad, _stream(dev)), 'conv_dgrad')
+        return dx
+
     def sgd_chunk(self):
         return _lib.lib().deepipr_sgd_momentum_chunk()
 
@@ -819,24 +856,55 @@ class _SignLoss(torch.autograd.Function):
         return kernels.sign_loss_bwd(dloss.contiguous(), gamma, b, alpha, MARGIN, l2), None, None, None
 
 
-def _conv_fwd(x_in, w, stride, pad):
-    return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
+# The data convolution (models/layers/passportconv2d.py:218, conv2d.py:31).  Three kernels of this library stand in for the
+# vendor library where they measured faster on MI355X (tools/conv_bench.py, tools/wgrad_bench.py):
+#   weight gradient     deepipr_conv_wgrad   every 3x3 convolution of stride 1 / 2 it supports
+#   forward             deepipr_conv_fwd     the stride-2 convolutions (3x3 and 1x1): MIOpen wraps its NHWC solvers for
+#                                            them in layout transposes and zero fills; the stride-1 3x3 stays on MIOpen's
+#                                            Winograd kernels (at par with the direct fp32-MFMA kernel here)
+#   backward-data       deepipr_conv_dgrad   the 1x1 stride-2 shortcuts
+# DEEPIPR_OWN_CONV = auto (default) | all (every shape the kernels support) | 0 (vendor library only);
+# DEEPIPR_OWN_WGRAD=0 switches only the weight gradient off.  All three are bit-reproducible.
+OWN_CONV = os.environ.get('DEEPIPR_OWN_CONV', 'auto')
+OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0' and OWN_CONV != '0'
 
 
-# The weight gradient of the data convolution: this library's fp32-MFMA kernel (deepipr_conv_wgrad) wherever its shapes
-# reach -- NCHW in, OIHW out, no layout shims, bit-reproducible -- the vendor library's otherwise.
-# DEEPIPR_OWN_WGRAD=0 switches it off (A/B, triage).
-OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0'
+def _own_ok(t, w):
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and w.dim() == 4 and w.shape[2] == w.shape[3]
+
+
+def _own_fwd(x_in, w, stride, pad):
+    if OWN_CONV == '0' or not _own_ok(x_in, w) or (OWN_CONV != 'all' and stride == 1):
+        return False
+    n, ci, h, wd = x_in.shape
+    return kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
+
+
+def _own_dgrad(x_shape, w, stride, pad, dy):
+    # auto: the 1x1 stride-2 shortcuts only (18-23 us against 30-43); the 3x3 stride-2 backward-data as four parity classes
+    # stages its operands once per class and measures 95-116 us against the library's 93-96 (tools/conv_bench.py)
+    if OWN_CONV == '0' or not _own_ok(dy, w) or (OWN_CONV != 'all' and (stride == 1 or w.shape[2] != 1)):
+        return False
+    n, ci, h, wd = x_shape
+    return kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1)
 
 
 def _own_wgrad(x_in, w, stride, pad):
-    if not (OWN_WGRAD and x_in.is_cuda and x_in.dtype == torch.float32 and x_in.dim() == 4 and w.dim() == 4):
+    if not (OWN_WGRAD and _own_ok(x_in, w)):
         return False
     n, ci, h, wd = x_in.shape
     return bool(kernels.conv_wgrad_workspace(n, ci, w.shape[0], h, wd, w.shape[2], w.shape[3], stride, pad))
 
 
+def _conv_fwd(x_in, w, stride, pad):
+    if _own_fwd(x_in, w, stride, pad):
+        return kernels.conv_fwd(x_in, w, stride, pad)
+    return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
+
+
 def _conv_dgrad(dconv, x_in, w, stride, pad):
+    if _own_dgrad(x_in.shape, w, stride, pad, dconv):
+        return kernels.conv_dgrad(dconv, w, x_in.shape, stride, pad)
     return torch.ops.aten.convolution_backward(dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0],
                                                1, [True, False, False])[0]
 
@@ -855,8 +923,12 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
         dconv = dconv.contiguous()
         dx = _conv_dgrad(dconv, x_in, w, stride, pad) if need_dx else None
         return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
+    own_dx = need_dx and _own_dgrad(x_in.shape, w, stride, pad, dconv)
     dx, dw, _ = torch.ops.aten.convolution_backward(
-        dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [need_dx, need_dw, False])
+        dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+        [need_dx and not own_dx, need_dw, False])
+    if own_dx:
+        dx = kernels.conv_dgrad(dconv.contiguous(), w, x_in.shape, stride, pad)
     if need_dw:
         dw = dw.contiguous()
         if defer is not None:
@@ -866,10 +938,11 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     return dx, dw, False
 
 
-class _Conv2dOwnWgrad(torch.autograd.Function):
+class _Conv2dOwn(torch.autograd.Function):
     """`conv(x)` of a plain bias-free convolution (models/layers/conv2d.py:31; passportconv2d.py:218 when the data
-    convolution runs outside the fused node): forward and backward-data stay the vendor library's, the weight gradient
-    is deepipr_conv_wgrad."""
+    convolution runs outside the fused node) with this library's kernels wherever the policy above picks them -- forward
+    (deepipr_conv_fwd), backward-data (deepipr_conv_dgrad), weight gradient (deepipr_conv_wgrad) -- and the vendor library
+    for the rest, per direction."""
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
@@ -886,21 +959,34 @@ class _Conv2dOwnWgrad(torch.autograd.Function):
         if dy is None:
             return None, None, None, None
         dy = dy.contiguous()
-        dx = _conv_dgrad(dy, x, w, stride, pad) if ctx.needs_input_grad[0] else None
-        dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        if need_dw and _own_wgrad(x, w, stride, pad):
+            dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad)
+            need_dw = False
+        if need_dx and _own_dgrad(x.shape, w, stride, pad, dy):
+            dx = kernels.conv_dgrad(dy, w, x.shape, stride, pad)
+            need_dx = False
+        if need_dx or need_dw:
+            vdx, vdw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [1, 1], False,
+                                                              [0, 0], 1, [need_dx, need_dw, False])
+            dx = vdx if need_dx else dx
+            dw = vdw if need_dw else dw
         return dx, dw, None, None
 
 
 def conv2d(conv, x):
-    """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked whose weight gradient this library computes itself
-    goes through _Conv2dOwnWgrad; anything else is the module call."""
-    if (OWN_WGRAD and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+    """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked for which this library has a kernel in at least one
+    direction goes through _Conv2dOwn; anything else is the module call."""
+    if (OWN_CONV != '0' and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
             and conv.padding_mode == 'zeros' and conv.stride[0] == conv.stride[1]
             and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
+            and conv.kernel_size[0] == conv.kernel_size[1]
             and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or conv._backward_pre_hooks)
-            and type(conv) is torch.nn.Conv2d and torch.is_grad_enabled() and conv.weight.requires_grad
-            and _own_wgrad(x, conv.weight, conv.stride[0], conv.padding[0])):
-        return _Conv2dOwnWgrad.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+            and type(conv) is torch.nn.Conv2d):
+        st, pd, w = conv.stride[0], conv.padding[0], conv.weight
+        if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)):
+            return _Conv2dOwn.apply(x, w, st, pd)
     return conv(x)
 
 

@@ -81,7 +81,9 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_GN_BWD 20
 #define DEEPIPR_K_CONV_WGRAD 21         /* `bytes` of this slot are FLOPs: its roofline is the fp32 MFMA peak */
 #define DEEPIPR_K_CONV_WGRAD_REDUCE 22
-#define DEEPIPR_PROFILE_KERNELS 23
+#define DEEPIPR_K_CONV_FWD 23           /* FLOPs, like DEEPIPR_K_CONV_WGRAD */
+#define DEEPIPR_K_CONV_DGRAD 24
+#define DEEPIPR_PROFILE_KERNELS 25
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -427,6 +429,29 @@ size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, i
 int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci, int Co, int H, int W, int kh, int kw,
                        int stride, int pad, const float *dgamma, const float *dbeta, const double *m, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ data convolution: forward / backward-data
+ * y[n][co][oh][ow] = sum_{ci,r,s} w[co][ci][r][s] * x[n][ci][oh*stride + r - pad][ow*stride + s - pad]      (conv_fwd)
+ * dx[n][ci][ih][iw] = sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(ih + pad - r) / stride][(iw + pad - s) / stride]
+ *                                                   over the (r, s) for which the divisions are exact      (conv_dgrad)
+ * as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NCHW in and out: no layout conversion, no
+ * workspace, bit-reproducible (fixed summation order).  Backward-data gathers the transposed (stride 1: and flipped)
+ * weights while it stages them -- there is no transposed copy of w -- and runs a stride-2 convolution as its four output
+ * parity classes in one launch (no multiplication by inserted zeros; the 1x1 case writes the zero pixels itself).
+ * Supported (deepipr_conv_supported; direction 0 = forward, 1 = backward-data): Ci, Co multiples of 64;
+ *   3x3 pad 1 stride 1 on output maps 4 / 8 / 16 / 32 wide (both directions),
+ *   3x3 pad 1 stride 2 and 1x1 pad 0 stride 2 on output maps 4 / 8 / 16 wide (both directions; 3x3 backward-data also 32);
+ *   whole row bands: the output height a multiple of 8 / 8 / 4 / 2 (32-, 16-, 8-, 4-wide maps), N a multiple of 4 on 4-wide maps.
+ * Anything else returns DEEPIPR_EUNSUPPORTED without enqueuing anything: the caller keeps the library's convolution.
+ * replaces: aten::convolution / the data half of aten::convolution_backward behind `self.conv(x)`,
+ *           models/layers/passportconv2d.py:218 (private twin :215), models/layers/conv2d.py:31 -- for the stride-2
+ *           and 1x1 convolutions MIOpen's igemm_{fwd,bwd}_gtcx35_nhwc + batched_transpose_* + SubTensorOpWithScalar1d.
+ * H, W: the convolution's INPUT map (x) in both calls.   x [N][Ci][H][W]   w [Co][Ci][k][k]   y, dy [N][Co][H/stride][W/stride] */
+int deepipr_conv_supported(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction);
+int deepipr_conv_fwd(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
+                     void *stream);
+int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
+                       int pad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,124 @@
+"""deepipr_conv_fwd / deepipr_conv_dgrad -- the data convolution and its backward-data on the fp32 matrix cores -- against
+the oracle: ATen's convolution / convolution_backward evaluated in float64 (what `self.conv(x)`,
+models/layers/passportconv2d.py:218 / models/layers/conv2d.py:31, and its autograd backward compute in the reference).
+Bar: 1e-5 of the result's scale (fp32 accumulation over up to 4 608 products; measured 2e-7 - 1.2e-6), bit-reproducible."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def K():
+    from deepipr_amd.passport_ops import kernels
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    return kernels
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV)
+
+
+def _conv64(x, w, st, pad):
+    return torch.ops.aten.convolution(x.double(), w.double(), None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
+
+
+def _dgrad64(dy, x, w, st, pad):
+    return torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [pad, pad], [1, 1], False,
+                                               [0, 0], 1, [True, False, False])[0]
+
+
+# (N, Ci, Co, H, W of the input, k, stride): every instance of the kernel family -- large / small position counts
+# (row-band vs k-group tiles), Ci != Co, the config R and config P shard shapes of ResNet18
+SHAPES = [
+    (128, 64, 64, 32, 32, 3, 1), (8, 64, 128, 32, 32, 3, 1), (128, 128, 128, 16, 16, 3, 1), (4, 128, 64, 16, 16, 3, 1),
+    (128, 256, 256, 8, 8, 3, 1), (3, 256, 128, 8, 8, 3, 1), (128, 512, 512, 4, 4, 3, 1), (4, 192, 64, 4, 4, 3, 1),
+    (32, 64, 64, 32, 32, 3, 1), (32, 512, 512, 4, 4, 3, 1),
+    (128, 64, 128, 32, 32, 3, 2), (3, 64, 64, 32, 32, 3, 2), (128, 128, 256, 16, 16, 3, 2), (5, 128, 64, 16, 16, 3, 2),
+    (128, 256, 512, 8, 8, 3, 2), (4, 256, 64, 8, 8, 3, 2), (32, 256, 512, 8, 8, 3, 2),
+    (128, 64, 128, 32, 32, 1, 2), (2, 64, 64, 32, 32, 1, 2), (128, 128, 256, 16, 16, 1, 2), (128, 256, 512, 8, 8, 1, 2),
+    (4, 256, 64, 8, 8, 1, 2), (2, 64, 64, 16, 32, 3, 1), (2, 64, 64, 16, 32, 3, 2),
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_forward_and_backward_data_match_the_float64_oracle(K, shape):
+    n, ci, co, h, w, k, st = shape
+    pad = k // 2
+    x, wt = _rand((n, ci, h, w), 1 + n), _rand((co, ci, k, k), 2 + co, 0.05)
+    dy = _rand((n, co, h // st, w // st), 3 + ci)
+    y = K.conv_fwd(x, wt, st, pad)
+    assert y is not None and y.shape == (n, co, h // st, w // st)
+    ref = _conv64(x, wt, st, pad)
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(y, K.conv_fwd(x, wt, st, pad))
+    dx = K.conv_dgrad(dy, wt, x.shape, st, pad)
+    assert dx is not None and dx.shape == x.shape
+    ref = _dgrad64(dy, x, wt, st, pad)
+    assert float((dx.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, st, pad))
+
+
+@pytest.mark.parametrize('k,st', [(3, 1), (3, 2), (1, 2)])
+def test_one_hot_operands_are_exact(K, k, st):
+    """Small-integer one-hot inputs: every output is a single product (or a short exact sum), so a wrong tap, a halo that
+    is not zero, a parity class written to the wrong pixel or a band leaking into its neighbour is an exact mismatch."""
+    n, c, h, pad = 4, 64, 8 * st, k // 2
+    rs = np.random.RandomState(k + st)
+    x = torch.zeros(n, c, h, h, device=DEV)
+    dy = torch.zeros(n, c, h // st, h // st, device=DEV)
+    w = torch.zeros(c, c, k, k, device=DEV)
+    for _ in range(200):
+        x[rs.randint(n), rs.randint(c), rs.choice([0, h - 1, rs.randint(h)]), rs.choice([0, h - 1, rs.randint(h)])] = float(rs.randint(1, 5))
+        dy[rs.randint(n), rs.randint(c), rs.randint(h // st), rs.randint(h // st)] = float(rs.randint(1, 5))
+    for _ in range(600):
+        w[rs.randint(c), rs.randint(c), rs.randint(k), rs.randint(k)] = float(rs.randint(1, 4))
+    y, dx = K.conv_fwd(x, w, st, pad), K.conv_dgrad(dy, w, x.shape, st, pad)
+    ry, rdx = _conv64(x, w, st, pad), _dgrad64(dy, x, w, st, pad)
+    assert float(ry.abs().sum()) > 0 and float(rdx.abs().sum()) > 0
+    assert torch.equal(y.double(), ry) and torch.equal(dx.double(), rdx)
+
+
+@pytest.mark.parametrize('case', [dict(ci=3, co=64), dict(ci=64, co=96), dict(h=14), dict(k=5, pad=2), dict(k=1, pad=0, st=1),
+                                  dict(h=64, st=2), dict(n=3, h=4), dict(k=3, pad=0)])
+def test_shapes_outside_the_kernels_are_refused(K, case):
+    n, ci, co, h = case.get('n', 4), case.get('ci', 64), case.get('co', 64), case.get('h', 8)
+    k, st = case.get('k', 3), case.get('st', 1)
+    pad = case.get('pad', k // 2)
+    assert not K.conv_supported(n, ci, co, h, h, k, st, pad, 0)
+    x, w = _rand((n, ci, h, h), 1), _rand((co, ci, k, k), 2)
+    assert K.conv_fwd(x, w, st, pad) is None
+    if not (case.get('h') == 64):                           # the 3x3 stride-2 backward-data also takes 32-wide dy maps
+        assert not K.conv_supported(n, ci, co, h, h, k, st, pad, 1)
+
+
+def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
+    """A residual block with a projection (stride-2 3x3 + stride-1 3x3 + 1x1 stride-2 shortcut) through DEEPIPR_OWN_CONV =
+    all / auto / 0: same outputs and gradients within 2e-5 of scale (different summation orders), and the kernels that
+    ran are the ones the policy names."""
+    from deepipr_amd import _lib
+    from deepipr_amd import passport_ops as P
+    from deepipr_amd.models.resnet_passport import BasicPassportBlock
+    kw = {name: {'flag': False, 'norm_type': 'bn'} for name in ('convbnrelu_1', 'convbn_2', 'shortcut')}
+    res = {}
+    for mode in ('all', 'auto', '0'):
+        monkeypatch.setattr(P, 'OWN_CONV', mode)
+        monkeypatch.setattr(P, 'OWN_WGRAD', mode != '0')
+        torch.manual_seed(0)
+        blk = BasicPassportBlock(64, 128, 2, kw).to(DEV)
+        x = _rand((32, 64, 32, 32), 9).requires_grad_(True)
+        _lib.profile_enable(True)
+        y = blk(x)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        res[mode] = (y.detach(), x.grad, [p.grad for p in blk.parameters()],
+                     tuple(int(prof[k][1]) for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad')))
+    assert res['all'][3] == (3, 3, 2) and res['auto'][3] == (2, 1, 2) and res['0'][3] == (0, 0, 0)
+    for mode in ('all', 'auto'):
+        for a, b in zip([res[mode][0], res[mode][1]] + res[mode][2], [res['0'][0], res['0'][1]] + res['0'][2]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9
