@@ -1,4 +1,4 @@
-"""The exchange time-out cases of tests/test_round2_gpu.py::test_exchange_timeout_is_loud, run in a process that
+"""The exchange time-out cases of tests/test_norm_kernels_gpu.py::test_exchange_timeout_is_loud, run in a process that
 loaded the measurement / test build of the library (DEEPIPR_LIB=.../libdeepipr_hip_trace.so): only that build has the
 hooks that force a time-out (deepipr_debug_tune: exchange_drop, exchange_spin)."""
 import os

@@ -397,7 +397,7 @@ def test_force_passport_paths(golden_dir, cpu_kernels):
 @pytest.mark.parametrize('name', ['bk3_s2', 'bn_s1', 'sc_1x1'])
 def test_trainable_keys_match_reference_autograd(name, golden_dir, cpu_kernels):
     """Keys as nn.Parameters (passport_attack_3.py:232-243): the product's autograd wiring of d/dkey, d/dskey and the
-    three-way dW against the REFERENCE's own autograd (goldens blocks.npz: dkey/*).  GPU twin: test_round2_gpu.py."""
+    three-way dW against the REFERENCE's own autograd (goldens blocks.npz: dkey/*).  GPU twin: test_passport_layer_gpu.py."""
     from tests.blocks import run_dkey_case
     gold = load_golden(golden_dir, 'blocks')
     got = run_dkey_case(name, 'cpu')

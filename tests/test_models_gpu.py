@@ -1,0 +1,416 @@
+"""Whole nets on the GPU against the oracle: full-size steps of the BASELINE configurations, the whole-net backward at 1e-4
+of scale with the ReLU kinks gated, the shared trunk of the V2 / V3 dual forward, the dual form at model level."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import patterns, torch_ref
+from oracle.cases import ALPHA, SGD, alexnet_config
+from tests.compare import close, states_close
+from tests.gpu_common import DEV, K, dev, host, pinned_miopen      # noqa: F401  (K is a fixture)
+from tests.impls import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- full-size configurations
+def _state_close(prod, ref, rtol=1e-3, atol=2e-4):
+    sd_p, sd_r = prod.state_dict(), ref.state_dict()
+    for k in sd_r:
+        if sd_r[k].dtype.is_floating_point:
+            assert torch.allclose(sd_p[k].cpu(), sd_r[k], rtol=rtol, atol=atol), k
+
+
+def test_resnet18_v3_full_size_step_with_trigger_pair():
+    """BASELINE config 4 shard: ResNet18 V3 (--train-backdoor), 64 images + the 2 trigger images per step
+    (experiments/trainer_private.py:135-146, dataset.py:188-191) = a ragged batch of 66 through the dual-branch step."""
+    from deepipr_amd.experiments.trainer_private import DualBranch, TesterPrivate, train_step_v23
+    from tests.test_parity_gpu import _fullsize_pair
+    prod, ref, x, y = _fullsize_pair(True, 64, 100)
+    wm = patterns.batch(2, 3, 32, 32, 100, salt=1)
+    xs, ys = torch.cat([x, wm[0]]), torch.cat([y, wm[1]])
+    logits = []
+    h = prod.register_forward_hook(lambda m, i, o: logits.append(o.detach().cpu()))
+    opt_p = torch.optim.SGD(prod.parameters(), **SGD)
+    opt_r = torch.optim.SGD(ref.parameters(), **SGD)
+    loss, sign_loss, _, _ = train_step_v23(DualBranch(prod), opt_p, xs.to(DEV), ys.to(DEV))
+    h.remove()
+    out = torch_ref.v23_step(ref, opt_r, x, y, wm)
+    assert logits[0].shape == (66, 100)
+    assert torch.allclose(logits[0], out['pred_public'], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(logits[1], out['pred_private'], rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(out['loss'])) < 1e-4 and abs(float(sign_loss) - float(out['sign_loss'])) < 1e-4
+    sig_p = TesterPrivate(prod, torch.device(DEV), verbose=False).test_signature()
+    sig_r = torch_ref.signature_report(ref)
+    for k in sig_r:
+        assert sig_p[k] == pytest.approx(sig_r[k][1], abs=1e-7), k
+    _state_close(prod, ref)
+
+
+def test_alexnet_v1_full_size_step_batch_64():
+    """BASELINE config 0: AlexNet V1 (last three conv layers passported), CIFAR10 shapes, batch 64."""
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.alexnet_passport import AlexNetPassport
+    cfg = alexnet_config()
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': ALPHA})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prod = AlexNetPassport(3, 10, kw).to(DEV)
+    ref = torch_ref.AlexNetRef(3, 10, torch_ref.passport_kwargs_from_config(cfg, 'bn', 'random', ALPHA))
+    x, y = patterns.batch(64, 3, 32, 32, 10)
+    prod.train(), ref.train()
+    with torch.no_grad():
+        prod(x.to(DEV)), ref(x)
+    patterns.fill_state(prod), patterns.fill_state(ref)
+    logits = []
+    h = prod.register_forward_hook(lambda m, i, o: logits.append(o.detach().cpu()))
+    opt_p = torch.optim.SGD(prod.parameters(), **SGD)
+    opt_r = torch.optim.SGD(ref.parameters(), **SGD)
+    loss, sign_loss, _ = train_step_v1(prod, opt_p, x.to(DEV), y.to(DEV))
+    h.remove()
+    out = torch_ref.v1_step(ref, opt_r, x, y)
+    assert torch.allclose(logits[0], out['pred'], rtol=1e-4, atol=1e-4), (logits[0] - out['pred']).abs().max()
+    assert abs(float(loss) - float(out['loss'])) < 1e-4
+    assert abs(float(sign_loss) - float(out['sign_loss'])) < 1e-4
+    for name, m in ref.named_modules():
+        if isinstance(m, torch_ref.PassportLayerRef):
+            g_ref = m.sign_loss.scale_cache.detach().view(-1)
+            g_gpu = dict(prod.named_modules())[name].sign_loss.scale_cache.detach().view(-1).cpu()
+            assert torch.allclose(g_gpu, g_ref, rtol=1e-4, atol=1e-6)
+            assert torch.equal(g_gpu.sign(), g_ref.sign()), name
+    _state_close(prod, ref)
+
+
+def test_resnet50_bottleneck_passport_on_imagenet_shapes():
+    """BASELINE config 5: ResNet50 passport, 3x224x224, 1000 classes (7x7/2 stem + max-pool,
+    models/resnet_passport.py:94-98).  The reference has no passport Bottleneck; the build's variant runs the HIP
+    kernels here (3-launch norm forms on the 112..7 pixel maps, `_v4g` kernels on the 7x7 planes of the passported
+    layer4) against the oracle's Bottleneck composed from the reference-pinned blocks."""
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.resnet_passport import ResNet50Passport
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet50_passport.json')))
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': ALPHA})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prod = ResNet50Passport(num_classes=1000, passport_kwargs=kw).to(DEV)
+    ref = torch_ref.resnet50_ref(num_classes=1000, passport_kwargs=torch_ref.passport_kwargs_from_config(
+        cfg, 'bn', 'random', ALPHA))
+    n = 8
+    x, y = patterns.batch(n, 3, 224, 224, 1000)
+    prod.train(), ref.train()
+    with torch.no_grad():
+        prod(x.to(DEV)), ref(x)
+    patterns.fill_state(prod), patterns.fill_state(ref)
+    for m in prod.modules():
+        if hasattr(m, 'invalidate_key_cache'):
+            m.invalidate_key_cache()
+    out_p, out_r = prod(x.to(DEV)), ref(x)
+    scale = float(out_r.abs().max())
+    assert float((out_p.cpu() - out_r).abs().max()) <= 1e-3 * scale, (float((out_p.cpu() - out_r).abs().max()), scale)
+    passports = {nm: m for nm, m in prod.named_modules() if getattr(m, 'sign_loss', None) is not None
+                 and hasattr(m, 'conv')}
+    assert len(passports) == 10
+    for name, m in ref.named_modules():
+        if isinstance(m, torch_ref.PassportLayerRef):
+            g_ref = m.sign_loss.scale_cache.detach().view(-1)
+            g_gpu = passports[name].sign_loss.scale_cache.detach().view(-1).cpu()
+            assert torch.allclose(g_gpu, g_ref, rtol=1e-4, atol=1e-6), name
+            sure = g_ref.abs() > 1e-6
+            assert torch.equal(g_gpu.sign()[sure], g_ref.sign()[sure]), name            # signature bits
+    sp = sum(m.sign_loss.loss for m in passports.values())
+    sr = sum(m.loss for m in torch_ref.sign_losses(ref))
+    assert float(sp) == pytest.approx(float(sr), rel=1e-4)
+    (torch.nn.functional.cross_entropy(out_p, y.to(DEV)) + sp).backward()
+    (torch.nn.functional.cross_entropy(out_r, y) + sr).backward()
+    gp = dict(prod.named_parameters())
+    worst = {}
+    for name, p in ref.named_parameters():
+        d = gp[name].grad.cpu() - p.grad
+        rel_l2 = float(d.norm() / (p.grad.norm() + 1e-20))
+        rel_max = float(d.abs().max() / (p.grad.abs().max() + 1e-20))
+        worst[name] = (rel_l2, rel_max)
+        if name.startswith(('layer4', 'linear')):
+            # the passport layers and the classifier: element-wise, 1 % of the gradient's scale
+            assert rel_max <= 1e-2, (name, rel_max)
+        else:
+            # 40 layers of batch norm over a batch of 8 amplify fp32 rounding differences (MIOpen vs oneDNN) on the way
+            # back to the stem: bounded in the L2 sense (isolated elements reach ~5 % of the scale)
+            assert rel_l2 <= 5e-2 and rel_max <= 0.25, (name, rel_l2, rel_max)
+    bp = dict(prod.named_buffers())
+    for name, bb in ref.named_buffers():
+        if name.endswith(('running_mean', 'running_var')):
+            assert torch.allclose(bp[name].cpu(), bb, rtol=1e-3, atol=1e-5), name
+
+
+# ----------------------------------------------------------------------------- whole net, tight
+class _RecordingF:
+    """torch.nn.functional for oracle/torch_ref.py with relu() recording, per layer, which pre-activations sit within
+    `tol` of the ReLU kink."""
+
+    def __init__(self, state, tol):
+        self.state, self.tol = state, tol
+
+    def __getattr__(self, name):
+        return getattr(torch.nn.functional, name)
+
+    def relu(self, t, *a, **k):
+        name = self.state['current']
+        if name is not None and t.dim() == 4:
+            self.state['near'].setdefault(name, []).append(t.detach().abs() < self.tol)
+        return torch.relu(t)
+
+
+def _layer_modules(net, types):
+    return [(k, m) for k, m in net.named_modules() if isinstance(m, types)]
+
+
+@pytest.mark.miopen_pinned
+@pytest.mark.parametrize('private', [False, True])
+def test_whole_net_backward_within_1e4_with_relu_kinks_gated(private, monkeypatch):
+    """ResNet18 V1 (batch 128) / V2 (batch 32, both branches, one backward) on the GPU against the float64 oracle
+    (stock ATen, oracle/torch_ref.py, same weights / keys / batch): logits, losses and EVERY parameter gradient within
+    1e-4 of its scale -- the north-star tolerance applied to a whole-net backward pass.
+
+    Two correct implementations may mask an activation that sits within rounding of a ReLU kink differently, and one
+    flipped mask perturbs every gradient upstream of it at the 1e-3 level (tests/triage/debug_hooks.py), which is why
+    the older model-level tests carry loose bounds.  Here the kinks are removed from the comparison the way
+    test_passport_block_backward_chain_at_config_R_shape does for one layer: a first float64 forward finds, per layer,
+    the pre-activations within 1e-4 of zero; both nets then run with those elements of the layer's output gated to
+    zero (output * keep), so neither value nor gradient passes through a near-kink element.  Gated outputs are 0 or
+    >= 1e-4, so the block tails relu(a + b) have no near-kink elements of their own.  The product runs with the
+    separate tail kernels (DEEPIPR_TAIL_FUSION=0) so that every layer output exists to be gated; the fused tails are
+    bit-identical to them (test_tail_fusion_is_bit_identical_at_model_level)."""
+    from deepipr_amd.models._builders import PASSPORT_TYPES
+    from deepipr_amd.models.layers.conv2d import ConvBlock
+    from tests.test_parity_gpu import _fullsize_pair
+    monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
+    tol = 1e-4
+    n, ncls = (32, 100) if private else (128, 10)
+    prod, ref, x, y = _fullsize_pair(private, n, ncls)
+    ref = ref.double().to(DEV)
+    xg, yg = x.to(DEV), y.to(DEV)
+    x64 = xg.double()
+    ce = torch.nn.functional.cross_entropy
+    inds = (0, 1) if private else (None,)
+
+    def ref_forward():
+        return [ref(x64) if i is None else ref(x64, ind=i) for i in inds]
+
+    # ---- pass 1: where are the kinks (float64, no grad; the norm buffers are restored afterwards)
+    state = {'current': None, 'near': {}}
+    ref_layers = _layer_modules(ref, (torch_ref.ConvBlockRef, torch_ref.PassportLayerRef))
+    saved = {k: v.clone() for k, v in ref.state_dict().items()}
+    hooks = []
+    for name, m in ref_layers:
+        hooks.append(m.register_forward_pre_hook(lambda _m, _i, name=name: state.__setitem__('current', name)))
+        hooks.append(m.register_forward_hook(lambda _m, _i, _o: state.__setitem__('current', None)))
+    monkeypatch.setattr(torch_ref, 'F', _RecordingF(state, tol))
+    with torch.no_grad():
+        ref_forward()
+    monkeypatch.undo()
+    monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
+    for h in hooks:
+        h.remove()
+    ref.load_state_dict(saved)
+    near = state['near']
+    assert set(near) == {k for k, _ in ref_layers} and all(len(v) == len(inds) for v in near.values())
+    gated = sum(int(t.sum()) for v in near.values() for t in v)
+    total = sum(t.numel() for v in near.values() for t in v)
+    assert 0 < gated < 2e-3 * total, (gated, total)
+
+    # ---- pass 2: both nets with the near-kink outputs gated
+    def gate(masks, dtype):
+        calls = {'n': 0}
+
+        def hook(_m, _i, out):
+            keep = (~masks[calls['n'] % len(masks)]).to(dtype)
+            calls['n'] += 1
+            if isinstance(out, tuple):                          # a layer whose output is handed out twice (the stem)
+                return tuple(o * keep for o in out)
+            return out * keep
+        return hook
+    for name, m in ref_layers:
+        m.register_forward_hook(gate(near[name], torch.float64))
+    prod_layers = dict(_layer_modules(prod, PASSPORT_TYPES + (ConvBlock,)))
+    assert set(prod_layers) == set(near)
+    # ConvBlocks: a module hook sees the layer's own output (the tail add happens outside the module call).  Passport
+    # layers add the residual INSIDE their module call (_forward), so their own output is gated where it is produced.
+    from deepipr_amd.models.layers._passport_base import PassportLayerBase
+    gates = {}
+    for name, m in prod_layers.items():
+        if isinstance(m, ConvBlock):
+            m.register_forward_hook(gate(near[name], torch.float32))
+        else:
+            gates[id(m)] = gate(near[name], torch.float32)
+    inner = PassportLayerBase._layer
+
+    def gated_layer(self, x_in, force_passport, ind, residual, conv_out=None):
+        out = inner(self, x_in, force_passport, ind, residual, conv_out)
+        g = gates.get(id(self))
+        return out if g is None else g(self, None, out)
+    monkeypatch.setattr(PassportLayerBase, '_layer', gated_layer)
+
+    outs_r = ref_forward()
+    loss_r = sum(ce(o, yg) for o in outs_r)
+    sign_r = sum(m.loss for m in torch_ref.sign_losses(ref) if isinstance(m.loss, torch.Tensor))
+    (loss_r + sign_r).backward()
+    with pinned_miopen():
+        outs_p = [prod(xg) if i is None else prod(xg, ind=i) for i in inds]
+        loss_p = sum(ce(o, yg) for o in outs_p)
+        if private:
+            sign_p = sum(m.sign_loss_private.loss for m in prod.modules() if hasattr(m, 'sign_loss_private'))
+        else:
+            sign_p = sum(m.sign_loss.loss for m in prod.modules()
+                         if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+        (loss_p + sign_p).backward()
+        torch.cuda.synchronize()
+
+    for op, orf in zip(outs_p, outs_r):
+        scale = max(1.0, float(orf.abs().max()))
+        assert float((op.double() - orf).abs().max()) <= 1e-4 * scale
+    assert abs(float(loss_p) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
+    assert abs(float(sign_p) - float(sign_r)) <= 1e-4 * max(1.0, abs(float(sign_r)))
+    gp = dict(prod.named_parameters())
+    worst = (0.0, None)
+    for name, p in ref.named_parameters():
+        assert p.grad is not None and gp[name].grad is not None, name
+        scale = float(p.grad.abs().max()) + 1e-30
+        rel = float((gp[name].grad.double() - p.grad).abs().max()) / scale
+        worst = max(worst, (rel, name))
+        assert rel <= 1e-4, (name, rel, scale)
+    print('whole-net backward, kinks gated (%d of %d activations): worst gradient error %.2e of scale (%s)'
+          % (gated, total, worst[0], worst[1]))
+
+
+# ----------------------------------------------------------------------------- shared trunk of the V2 / V3 dual forward
+@pytest.mark.parametrize('graph', [False, True])
+def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
+    """ResNet18 V2 (config P shard: batch 32, 100 classes): the layers in front of layer4 run once for both branches
+    (models/_builders.shared_trunk) against the two full passes (DEEPIPR_NO_SHARED_TRUNK=1), eagerly and replayed from
+    the whole-step hipGraph (one eager step / seven replayed ones); logits-derived scalars, every parameter and every buffer (running
+    statistics after TWO updates per step, num_batches_tracked) agree -- gradients differ only by the association of
+    the two branches' sum."""
+    from deepipr_amd.experiments.graph_step import GraphedTrainStep
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.flat_sgd import FlatSGD
+    from deepipr_amd.models.resnet_passport_private import ResNet18Private
+    from oracle.cases import resnet18_config
+    kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(32, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 100, (32,), generator=g).to(DEV)
+    res = {}
+    with pinned_miopen():
+        for mode in ('shared', 'twice'):
+            if mode == 'twice':
+                monkeypatch.setenv('DEEPIPR_NO_SHARED_TRUNK', '1')
+            else:
+                monkeypatch.delenv('DEEPIPR_NO_SHARED_TRUNK', raising=False)
+            torch.manual_seed(4)
+            np.random.seed(4)
+            net = ResNet18Private(num_classes=100, passport_kwargs=kw).to(DEV)
+            net.train()
+            with torch.no_grad():
+                net(x)
+            dual = DualBranch(net)
+            opt = FlatSGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+            calls = {'n': 0}
+            net.convbnrelu_1.conv.register_forward_hook(lambda *_a: calls.__setitem__('n', calls['n'] + 1))
+            if graph:
+                net.convbnrelu_1.conv._forward_hooks.clear()       # no Python side effects inside a capture
+                step = GraphedTrainStep(train_step_v23, dual, opt, x, y)
+                outs = [tuple(float(v) for v in step(x, y)) for _ in range(3)]
+            else:
+                outs = [tuple(float(v) for v in train_step_v23(dual, opt, x, y))]       # ONE step: see the bars below
+            torch.cuda.synchronize()
+            res[mode] = dict(outs=outs, state={k: v.detach().clone() for k, v in net.state_dict().items()},
+                             calls=calls['n'])
+    a, b = res['shared'], res['twice']
+    if not graph:
+        assert (a['calls'], b['calls']) == (1, 2), (a['calls'], b['calls'])     # the trunk really runs once per step
+    if not graph:
+        assert a['outs'][0] == b['outs'][0], (a['outs'][0], b['outs'][0])  # first step: identical forward, bit for bit
+    for u, v in zip(a['outs'], b['outs']):
+        if graph:                                  # top-1 (steps of 100 / 32 %) may flip on a near-tie after seven steps
+            u, v = u[:2], v[:2]
+        assert np.allclose(u, v, rtol=1e-3 if graph else 1e-4, atol=1e-4 if graph else 1e-5), (u, v)
+    for k, v in b['state'].items():
+        if k.endswith('num_batches_tracked'):
+            assert int(a['state'][k]) == int(v), k
+        else:
+            # The association of the two branches' sum (a few 1e-6 of the gradient scale) is the only difference after
+            # ONE step (eager variant: 1e-8 absolute in the parameters).  From there it grows by orders of magnitude per
+            # step -- early training, gradients of O(10) from a sign loss of ~30: 7e-9 after one step, 8e-6 after three,
+            # 4e-5 after seven on the CPU; 1e-4 after three on the GPU -- so only the one-step comparison is tight.  The
+            # replayed variant has run seven steps by now (three warm-up steps, the captured one, three replays): its bar
+            # is the trajectory tests' one.
+            worst = float((a['state'][k] - v).abs().max())
+            rel, ab = (5e-3, 2e-4) if graph else (1e-4, 5e-5)
+            assert worst <= rel * float(v.abs().max()) + ab, (k, worst)
+
+
+@pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2'])
+def test_dual_tail_is_bit_identical_at_model_level(K, net_kind, monkeypatch):
+    """ResNet18: layer2.0 and layer3.0 (plain ConvBlocks: convbn_2 + projection shortcut) take the dual form by
+    default; DEEPIPR_NO_DUAL_TAIL=1 runs the two layers one after the other.  Logits and every parameter gradient
+    bit-identical with MIOpen pinned, two fused launches less per direction."""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.resnet_passport import ResNet18Passport
+    from deepipr_amd.models.resnet_passport_private import ResNet18Private
+    from oracle.cases import resnet18_config
+    private = net_kind.endswith('v2')
+    kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    torch.manual_seed(3)
+    np.random.seed(3)
+    net = (ResNet18Private if private else ResNet18Passport)(num_classes=10, passport_kwargs=kw).to(DEV)
+    net.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(128, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (128,), generator=g).to(DEV)
+    with torch.no_grad():
+        net(x)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    ce = torch.nn.functional.cross_entropy
+
+    def step(off):
+        if off:
+            monkeypatch.setenv('DEEPIPR_NO_DUAL_TAIL', '1')
+        else:
+            monkeypatch.delenv('DEEPIPR_NO_DUAL_TAIL', raising=False)
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        _lib.profile_enable(True)
+        if private:
+            outs = list(net.forward_dual(x))
+            loss = ce(outs[0], y) + ce(outs[1], y) + sum(m.sign_loss_private.loss for m in net.modules()
+                                                         if hasattr(m, 'sign_loss_private'))
+        else:
+            outs = [net(x)]
+            loss = ce(outs[0], y) + sum(m.sign_loss.loss for m in net.modules()
+                                        if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+        loss.backward()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        got = {'logits%d' % i: o.detach().clone() for i, o in enumerate(outs)}
+        got.update({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        got.update({'buf/' + k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+        return got, int(prof['bn_res_fwd'][1]), int(prof['bn_res_bwd'][1])
+
+    with pinned_miopen():
+        dual, f0, b0 = step(False)
+        separate, f1, b1 = step(True)
+    assert (f1 - f0, b1 - b0) == (2, 2), ((f0, b0), (f1, b1))
+    diff = {k: float((dual[k] - separate[k]).abs().max()) for k in dual if not torch.equal(dual[k], separate[k])}
+    assert not diff, '%d tensors differ: %s' % (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:4])

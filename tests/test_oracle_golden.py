@@ -146,7 +146,7 @@ def test_dkey_matches_reference_autograd(name, golden_dir):
 def test_reference_signs_on_near_zero_rows_document_the_noise_floor(golden_dir):
     """The adversarial fixture (goldens blocks.npz: nearzero/*): above 8 eps * sum|W_k m_k| the reference's own fp32
     gamma has the sign of the exact sum on every row; below it the reference flips some signs itself.  This is the
-    regime split the GPU test (test_round2_gpu.py) relies on."""
+    regime split the GPU test (test_passport_layer_gpu.py) relies on."""
     gold = load_golden(golden_dir, 'blocks')
     w, skey, g_ref = gold['nearzero/w'], gold['nearzero/skey'], gold['nearzero/gamma_ref']
     co = w.shape[0]

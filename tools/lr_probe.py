@@ -1,5 +1,5 @@
 """Eager vs replayed trajectory of the ResNet18 V1 step (FlatSGD, lr 0.05 -> the setting of
-tests/test_round2_gpu.py::test_graph_replay_follows_the_lr_schedule, which was seen to fail once right after the
+tests/test_train_step_gpu.py::test_graph_replay_follows_the_lr_schedule, which was seen to fail once right after the
 whole-net parity tests): after EVERY step the two models' parameters are compared bit by bit.  The two paths run the same
 kernels on the same inputs, so they must stay bit-identical; the first step at which they do not, and the tensors that
 differ first, localise a nondeterminism.   python tools/lr_probe.py [--reps 10] [--prelude]"""
@@ -22,7 +22,7 @@ def main():
     args = ap.parse_args()
     if args.prelude:
         import pytest
-        pytest.main(['-q', '-x', '-p', 'no:cacheprovider', os.path.join(ROOT, 'tests', 'test_round3_gpu.py'), '-k', 'whole_net'])
+        pytest.main(['-q', '-x', '-p', 'no:cacheprovider', os.path.join(ROOT, 'tests', 'test_models_gpu.py'), '-k', 'whole_net'])
     from deepipr_amd.experiments.graph_step import GraphedTrainStep
     from deepipr_amd.experiments.trainer import train_step_v1
     from deepipr_amd.flat_sgd import FlatSGD
