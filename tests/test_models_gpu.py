@@ -414,3 +414,112 @@ def test_dual_tail_is_bit_identical_at_model_level(K, net_kind, monkeypatch):
     assert (f1 - f0, b1 - b0) == (2, 2), ((f0, b0), (f1, b1))
     diff = {k: float((dual[k] - separate[k]).abs().max()) for k in dual if not torch.equal(dual[k], separate[k])}
     assert not diff, '%d tensors differ: %s' % (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:4])
+
+
+@pytest.mark.parametrize('shared', [True, False])
+def test_three_eager_v2_steps_follow_the_float64_oracle(K, shared, monkeypatch):
+    """ResNet18 V2 (config P shard: batch 32, 100 classes), THREE eager steps of the product's train step -- with the shared
+    trunk / shared first convolution of the dual forward (the default) and with the two full passes -- against three steps
+    of the oracle's v23_step (trainer_private.py:131-177) in float64 on the same weights, keys and batch: per step both
+    branches' logits within 1e-4 of scale, CE and sign loss within 1e-4 (the north star's bar, held over three steps);
+    after the third step every parameter and running statistic within 2e-3 of its scale (fp32 against float64 through
+    three SGD steps over batch-32 norm statistics; measured worst 3.6e-4, the stem's weight).  (VERDICT r03 next #2: the three-step comparison used to be a
+    self-comparison shared-vs-twice, cut to one step; an oracle comparison does not need that cut.)"""
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from tests.test_parity_gpu import _fullsize_pair
+    if not shared:
+        monkeypatch.setenv('DEEPIPR_NO_SHARED_TRUNK', '1')
+    prod, ref, x, y = _fullsize_pair(True, 32, 100)
+    ref = ref.double().to(DEV)
+    xg, yg = x.to(DEV), y.to(DEV)
+    seen = []
+    prod.register_forward_hook(lambda _m, _i, o: seen.append(o.detach().double()))
+    dual = DualBranch(prod)
+    opt_p = torch.optim.SGD(prod.parameters(), **SGD)
+    opt_r = torch.optim.SGD(ref.parameters(), **SGD)
+    worst = {'logits': 0.0, 'loss': 0.0}
+    for step in range(3):
+        del seen[:]
+        out_p = [float(v) for v in train_step_v23(dual, opt_p, xg, yg)]
+        out_r = torch_ref.v23_step(ref, opt_r, xg.double(), yg)
+        torch.cuda.synchronize()
+        assert len(seen) == 2
+        for got, want in zip(seen, (out_r['pred_public'], out_r['pred_private'])):
+            err = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
+            worst['logits'] = max(worst['logits'], err)
+            assert err <= 1e-4, (step, err)
+        for got, want in ((out_p[0], float(out_r['loss'])), (out_p[1], float(out_r['sign_loss']))):
+            err = abs(got - want) / max(1.0, abs(want))
+            worst['loss'] = max(worst['loss'], err)
+            assert err <= 1e-4, (step, got, want)
+    sp, sr = prod.state_dict(), ref.state_dict()
+    worst_p = (0.0, None)
+    for k, v in sr.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(sp[k]) == int(v), k
+            continue
+        if v.dtype not in (torch.float64, torch.float32) or k not in sp:
+            continue
+        err = float((sp[k].double() - v).abs().max()) / (float(v.abs().max()) + 1e-12)
+        worst_p = max(worst_p, (err, k))
+        assert err <= 2e-3, (k, err)
+    print('three V2 steps (%s): worst logits %.1e, losses %.1e, state %.1e (%s)'
+          % ('shared trunk' if shared else 'two passes', worst['logits'], worst['loss'], worst_p[0], worst_p[1]))
+
+
+def test_resnet18_imagenet_geometry_at_batch_64_takes_the_channel_range_passes():
+    """ResNet18 V1 on 3 x 224 x 224 inputs at batch 64 (BASELINE config 5's map sizes at a real batch: the stem's
+    [64, 64, 112, 112] activation is 205 MB, far beyond the register file): the fused norm kernels run as channel-range
+    passes of the single-pass form (deepipr_passport_bn_passes > 1) THROUGH THE MODEL, against the oracle in float64 on
+    the GPU -- logits and losses within 1e-4 of scale, every parameter gradient within 1e-2 in the L2 sense (no kink
+    gating here: flipped ReLU masks and max-pool ties among 51 M stem activations; measured worst 3.8e-3, the stem's
+    weight), running statistics within 1e-4.
+    (VERDICT r03 next #7; reference geometry: models/resnet_passport.py:94-98.)"""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.resnet_passport import ResNet18Passport
+    from oracle.cases import resnet18_config
+    n, ncls = 64, 100
+    lib = _lib.lib()
+    assert lib.deepipr_passport_bn_passes(n, 64, 112 * 112, 0) >= 2 and lib.deepipr_passport_bn_passes(n, 64, 56 * 56, 1) >= 2
+    cfg = resnet18_config()
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': ALPHA})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prod = ResNet18Passport(num_classes=ncls, passport_kwargs=kw, imagenet=True).to(DEV)
+    ref = torch_ref.resnet18_ref(num_classes=ncls, passport_kwargs=torch_ref.passport_kwargs_from_config(
+        cfg, 'bn', 'random', ALPHA), imagenet=True)
+    x, y = patterns.batch(n, 3, 224, 224, ncls)
+    prod.train(), ref.train()
+    with torch.no_grad():
+        prod(x[:2].to(DEV)), ref(x[:2])                         # keys
+    patterns.fill_state(prod), patterns.fill_state(ref)
+    for m in prod.modules():
+        if hasattr(m, 'invalidate_key_cache'):
+            m.invalidate_key_cache()
+    ref = ref.double().to(DEV)
+    xg, yg = x.to(DEV), y.to(DEV)
+    ce = torch.nn.functional.cross_entropy
+    out_p = prod(xg)
+    sp = sum(m.sign_loss.loss for m in prod.modules() if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv'))
+    (ce(out_p, yg) + sp).backward()
+    out_r = ref(xg.double())
+    sr = sum(m.loss for m in torch_ref.sign_losses(ref))
+    (ce(out_r, yg) + sr).backward()
+    torch.cuda.synchronize()
+    scale = max(1.0, float(out_r.detach().abs().max()))
+    assert float((out_p.detach().double() - out_r.detach()).abs().max()) <= 1e-4 * scale
+    assert abs(float(sp) - float(sr)) <= 1e-4 * max(1.0, abs(float(sr)))
+    gp = dict(prod.named_parameters())
+    worst = (0.0, None)
+    for name, p in ref.named_parameters():
+        d = gp[name].grad.double() - p.grad
+        rel = float(d.norm() / (p.grad.norm() + 1e-30))
+        worst = max(worst, (rel, name))
+        assert rel <= 1e-2, (name, rel)
+    bp = dict(prod.named_buffers())
+    for name, bb in ref.named_buffers():
+        if name.endswith(('running_mean', 'running_var')):
+            assert torch.allclose(bp[name].double(), bb, rtol=1e-4, atol=1e-6), name
+    print('ResNet18 224x224 batch 64: worst gradient error %.1e (L2, %s)' % worst)
