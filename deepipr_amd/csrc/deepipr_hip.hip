@@ -4184,18 +4184,21 @@ int conv_dgrad_s2(const float *dy, const float *w, float *dx, int N, int Ci, int
     if (!aligned16(w) || !aligned16(dy) || !aligned16(dx)) return fail(DEEPIPR_EINVAL, "conv_dgrad: pointers must be 16-byte aligned");
     ProfScope prof(DEEPIPR_K_CONV_DGRAD, st);
     prof.bytes = 2.0 * Ci * Co * k * k * static_cast<double>(N) * oh * ow;       // FLOPs
-    switch (p.cfg) {
-        case 11: launch_dgrad_s2<FwCfg<1, 9, 32, 8, 1, 4, 1, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
-        case 21: launch_dgrad_s2<FwCfg<1, 9, 32, 2, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
-        case 31: launch_dgrad_s2<FwCfg<1, 9, 16, 8, 1, 2, 2, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
-        case 41: launch_dgrad_s2<FwCfg<1, 9, 16, 4, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
-        case 51: launch_dgrad_s2<FwCfg<1, 9, 8, 8, 1, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
-        case 61: launch_dgrad_s2<FwCfg<1, 9, 4, 4, 4, 1, 4, 8>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
+#define DEEPIPR_DGRAD_X4(...)                                                                                         \
+    DEEPIPR_LAUNCH(prof, (k_conv_dgrad_s2x4<FwCfg<__VA_ARGS__>>), dim3(p.grid), dim3(256), st, w, dy, dx, Co, Ci, oh, p.bands)
+    switch (p.cfg) {                                               // W, RB, NIB, POSW, KG, CK, 32 positions per wave
+        case 11: DEEPIPR_DGRAD_X4(1, 9, 16, 8, 1, 4, 1, 8, 32); break;      // 128 positions per workgroup
+        case 21: DEEPIPR_DGRAD_X4(1, 9, 16, 4, 1, 2, 2, 8, 32); break;      // 64
+        case 31: DEEPIPR_DGRAD_X4(1, 9, 16, 2, 1, 1, 4, 8, 32); break;      // 32
+        case 41: DEEPIPR_DGRAD_X4(1, 9, 8, 8, 1, 2, 2, 8, 32); break;
+        case 51: DEEPIPR_DGRAD_X4(1, 9, 8, 4, 1, 1, 4, 8, 32); break;
+        case 61: DEEPIPR_DGRAD_X4(1, 9, 4, 4, 2, 1, 4, 8, 32); break;
         case 141: launch_dgrad_s2<FwCfg<1, 1, 16, 4, 1, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
         case 151: launch_dgrad_s2<FwCfg<1, 1, 8, 8, 1, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
         case 161: launch_dgrad_s2<FwCfg<1, 1, 4, 4, 4, 1, 4, 16>>(prof, p, w, dy, dx, Co, Ci, oh, st); break;
         default: return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: no instance");
     }
+#undef DEEPIPR_DGRAD_X4
     return check_launch("conv_dgrad");
 }
 }  // namespace

@@ -1,0 +1,21 @@
+#!/bin/bash
+# ONE parameterised entry for the GPU box (replaces round 3's twenty one-shot tools/gpu_r03_[a-t].sh, kept in git history).
+#   tools/gpu_run.sh suite [tag] [pytest args]       full `-m gpu` session -> gpurun_out/pytest_gpu_<tag>.log
+#   tools/gpu_run.sh tests <-k expression>           a subset, first failure stops
+#   tools/gpu_run.sh ab VAR=value [reps]             A/B of one environment switch on configs R / P shard / AlexNet
+#   tools/gpu_run.sh steady <tag> [bench args]       rocprofv3 kernel trace of the replayed step -> gpurun_out/<tag>.md
+#   tools/gpu_run.sh profiles <round tag>            the round's measurement set (steady states, ImageNet-shape lines)
+#   tools/gpu_run.sh bench <tag>                     bench lines R / V3 / P shard with their roofline objects
+#   tools/gpu_run.sh conv                            conv kernels (wgrad / fwd / dgrad) against the vendor library, per shape
+# Run through gpurun from the repo root:  gpurun --timeout 1800 -- 'tools/gpu_run.sh suite r04_final'
+cmd=$1; shift
+case "$cmd" in
+  suite)    exec tools/gpu_suite.sh "$@" ;;
+  tests)    exec timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "$1" ;;
+  ab)       exec tools/gpu_ab.sh "$@" ;;
+  steady)   exec tools/gpu_steady.sh "$@" ;;
+  profiles) exec tools/gpu_round_profiles.sh "$@" ;;
+  bench)    exec tools/gpu_bench_check.sh "$@" ;;
+  conv)     python tools/wgrad_bench.py --json gpurun_out/wgrad_bench.json | grep "^{"; exec python tools/conv_bench.py --json gpurun_out/conv_bench.json ;;
+  *)        sed -n 2,11p "$0"; exit 2 ;;
+esac
