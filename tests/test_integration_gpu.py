@@ -82,3 +82,30 @@ def test_reference_side_stub_of_integration_md_runs_on_the_gpu():
     close('dW', w1.grad, w3.grad, tol=1e-4)
     assert torch.equal(bits1.cpu().to(torch.float64), torch.sign(gamma3.detach().view(-1)).cpu())
     assert abs(float(loss1.detach()) - float(loss3.detach())) <= 1e-5 * max(1.0, abs(float(loss3.detach())))
+
+
+def test_section_c_convolution_stub_runs_on_the_gpu():
+    """the reference-side `Conv2dMI355X` Function (EXTRACTED from the document) on the three
+    kinds of convolution of a ResNet block -- 3x3 stride 1 (own weight gradient only), 3x3 stride 2 and 1x1 stride 2 (all
+    directions) -- against F.conv2d in float64: output, dx, dW within 1e-5 of scale."""
+    from deepipr_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    code = next(b for b in blocks if b.lstrip().startswith('# models/layers/_deepipr_conv.py'))
+    ns = {}
+    exec(compile(code.replace('/path/to/libdeepipr_hip.so', _lib.LIB_PATH), 'INTEGRATION.md#C', 'exec'), ns)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    for ci, co, h, k, st in ((64, 64, 16, 3, 1), (64, 128, 32, 3, 2), (64, 128, 32, 1, 2)):
+        pd = k // 2
+        x = torch.randn(8, ci, h, h, generator=g).to(dev).requires_grad_(True)
+        w = (0.05 * torch.randn(co, ci, k, k, generator=g)).to(dev).requires_grad_(True)
+        cot = torch.randn(8, co, h // st, h // st, generator=g).to(dev)
+        y = ns['Conv2dMI355X'].apply(x, w, st, pd)
+        (y * cot).sum().backward()
+        x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        y64 = torch.nn.functional.conv2d(x64, w64, None, st, pd)
+        (y64 * cot.double()).sum().backward()
+        for name, a, ref in (('y', y.detach(), y64.detach()), ('dx', x.grad, x64.grad), ('dW', w.grad, w64.grad)):
+            err = float((a.double() - ref).abs().max()) / max(1e-12, float(ref.abs().max()))
+            assert err <= 1e-5, (ci, co, h, k, st, name, err)
