@@ -860,9 +860,8 @@ class _SignLoss(torch.autograd.Function):
 # vendor library where they measured faster on MI355X (tools/conv_bench.py, tools/wgrad_bench.py):
 #   weight gradient     deepipr_conv_wgrad   every 3x3 convolution of stride 1 / 2 it supports
 #   forward             deepipr_conv_fwd     the stride-2 convolutions (3x3 and 1x1): MIOpen wraps its NHWC solvers for
-#                                            them in layout transposes and zero fills; the stride-1 3x3 stays on MIOpen's
+#   backward-data       deepipr_conv_dgrad   them in layout transposes and zero fills; the stride-1 3x3 stays on MIOpen's
 #                                            Winograd kernels (at par with the direct fp32-MFMA kernel here)
-#   backward-data       deepipr_conv_dgrad   the 1x1 stride-2 shortcuts
 # DEEPIPR_OWN_CONV = auto (default) | all (every shape the kernels support) | 0 (vendor library only);
 # DEEPIPR_OWN_WGRAD=0 switches only the weight gradient off.  All three are bit-reproducible.
 OWN_CONV = os.environ.get('DEEPIPR_OWN_CONV', 'auto')
@@ -873,20 +872,33 @@ def _own_ok(t, w):
     return t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and w.dim() == 4 and w.shape[2] == w.shape[3]
 
 
+# auto: a stride-2 3x3 convolution goes to the own forward / backward-data kernels when it has at least this many output
+# positions (N * OH * OW); below that (ResNet18's layer4.0 at batch <= 128, layer3.0 at batch <= 32) the 64 x 64-tile kernels
+# leave CUs idle and the vendor library, shims included, is as fast or faster (tools/conv_bench.py at batch 128 and 32,
+# profiles/r04_conv_bench*.json).  The 1x1 stride-2 shortcuts always win (8-21 us against 26-46).
+OWN_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_MIN_POSITIONS', 4096))
+
+
+def _own_policy(n, h, w, k, stride):
+    if OWN_CONV == 'all':
+        return True
+    if stride != 2:
+        return False
+    return k == 1 or n * (h // 2) * (w // 2) >= OWN_MIN_POSITIONS
+
+
 def _own_fwd(x_in, w, stride, pad):
-    if OWN_CONV == '0' or not _own_ok(x_in, w) or (OWN_CONV != 'all' and stride == 1):
+    if OWN_CONV == '0' or not _own_ok(x_in, w):
         return False
     n, ci, h, wd = x_in.shape
-    return kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
+    return _own_policy(n, h, wd, w.shape[2], stride) and kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
 
 
 def _own_dgrad(x_shape, w, stride, pad, dy):
-    # auto: the 1x1 stride-2 shortcuts only (18-23 us against 30-43); the 3x3 stride-2 backward-data as four parity classes
-    # stages its operands once per class and measures 95-116 us against the library's 93-96 (tools/conv_bench.py)
-    if OWN_CONV == '0' or not _own_ok(dy, w) or (OWN_CONV != 'all' and (stride == 1 or w.shape[2] != 1)):
+    if OWN_CONV == '0' or not _own_ok(dy, w):
         return False
     n, ci, h, wd = x_shape
-    return kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1)
+    return _own_policy(n, h, wd, w.shape[2], stride) and kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1)
 
 
 def _own_wgrad(x_in, w, stride, pad):
