@@ -647,7 +647,12 @@ def main():
             mfma = {'bound': 'mfma', 'kernel': 'k_conv3x3_wgrad (weight gradient of the 3x3 data convolutions, stride 1 / 2, on '
                     'v_mfma_f32_32x32x2_f32; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)',
                     'achieved': round(tf, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,
+                    # profiles/pmc_traffic.json): the inputs once or twice (row-band halos) + the 37.7 MB of split-K
+                    # partial tiles; an order of magnitude below what 80 us of HBM time could move -- MFMA-bound
+                    'traffic': pmc_traffic('k_conv3x3_wgrad', 'in_situ_per_launch') if args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32 else None,
+                    'traffic_source': 'profiles/pmc_traffic.json: k_conv3x3_wgrad (average over the 16 launches of a config-R step); matrix-core counters: profiles/r04_pmc_mfma_wgrad_bench.json (SQ_VALU_MFMA_BUSY_CYCLES = 64 x the MFMA count exactly)',
                     'flops_per_launch': int(flops / n), 'avg_us': round(1000.0 * ms / n, 2),
                     'launches_per_step': round(n / sampled, 1), 'us_per_step': round(1000.0 * ms / sampled, 1),
                     'reduce_us_per_step': round(1000.0 * rms / sampled, 1),
