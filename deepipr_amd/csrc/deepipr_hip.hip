@@ -4090,17 +4090,21 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     if (!x || !dy || !dW) return fail(DEEPIPR_EINVAL, "conv_wgrad: null pointer");
     const WgradPlan p = plan_wgrad(N, Ci, Co, H, W, kh, kw, stride, pad);
     if (!p.cfg)
-        return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: only 3x3 pad-1 convolutions of stride 1 / 2 with Ci, Co multiples of 64 "
-                    "and output maps 4/8/16/32 (stride 2: 4/8/16) wide (use the library's weight gradient)");
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: only 3x3 pad-1 convolutions of stride 1 / 2 and 1x1 pad-0 stride-2 ones, Ci, Co "
+                    "multiples of 64, output maps 4/8/16/32 (stride 2: 4/8/16) wide (use the library's weight gradient)");
     if (!workspace || workspace_bytes < p.workspace) return fail(DEEPIPR_EINVAL, "conv_wgrad: workspace too small");
     if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return fail(DEEPIPR_EINVAL, "conv_wgrad: pointers must be 16-byte aligned");
     const bool rank2 = dgamma || dbeta || m;
     if (rank2 && !(dgamma && dbeta && m)) return fail(DEEPIPR_EINVAL, "conv_wgrad: dgamma, dbeta and m go together");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *part = static_cast<float *>(workspace);
+    const int grid = p.splits * p.tiles_co * p.tiles_ci;
     {
         ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
-        prof.bytes = 2.0 * Co * Ci * 9.0 * N * (H / stride) * (W / stride);      // FLOPs, not bytes: this kernel's roofline is the MFMA peak
+        prof.bytes = 2.0 * Co * Ci * p.taps * static_cast<double>(N) * (H / stride) * (W / stride);     // FLOPs, not bytes: this kernel's roofline is the MFMA peak
+#define DEEPIPR_WGRAD_1X1(...)                                                                                        \
+    DEEPIPR_LAUNCH(prof, (k_conv1x1s2_wgrad<W1Cfg<__VA_ARGS__>>), dim3(grid), dim3(256), st, x, dy, part, Ci, Co, H,   \
+                   p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split)
         switch (p.cfg) {
             case 132: launch_wgrad<WgCfg<1, 32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 116: launch_wgrad<WgCfg<1, 16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
@@ -4108,22 +4112,30 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
             case 104: launch_wgrad<WgCfg<1, 4, 4, 2>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 216: launch_wgrad<WgCfg<2, 16, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 208: launch_wgrad<WgCfg<2, 8, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
-            default: launch_wgrad<WgCfg<2, 4, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 204: launch_wgrad<WgCfg<2, 4, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 1216: DEEPIPR_WGRAD_1X1(16, 4, 1); break;
+            case 1208: DEEPIPR_WGRAD_1X1(8, 8, 1); break;
+            case 1204: DEEPIPR_WGRAD_1X1(4, 4, 2); break;
+            default: return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no instance");
         }
+#undef DEEPIPR_WGRAD_1X1
     }
     const int tiles = p.tiles_co * p.tiles_ci;
     ProfScope prof(DEEPIPR_K_CONV_WGRAD_REDUCE, st);
-    prof.bytes = 4.0 * (static_cast<double>(p.splits) + 1.0) * tiles * kWgTile;
-#define DEEPIPR_WGRAD_REDUCE(SG, GRID, BLOCK)                                                                          \
+    prof.bytes = 4.0 * (static_cast<double>(p.splits) + 1.0) * tiles * 4096 * p.taps;
+#define DEEPIPR_WGRAD_REDUCE(SG, T, GRID, BLOCK)                                                                       \
     do {                                                                                                              \
-        if (rank2) DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, true>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,    \
+        if (rank2) DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, true, T>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci, \
                                   p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                     \
-        else DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, false>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,         \
+        else DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, false, T>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,      \
                             p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                           \
     } while (0)
-    if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, tiles * 144, 1024);
-    else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, tiles * 144, 256);
-    else DEEPIPR_WGRAD_REDUCE(1, tiles * 36, 256);
+    if (p.taps == 1) {
+        if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 1, tiles * 16, 256);
+        else DEEPIPR_WGRAD_REDUCE(1, 1, tiles * 4, 256);
+    } else if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, 9, tiles * 144, 1024);
+    else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 9, tiles * 144, 256);
+    else DEEPIPR_WGRAD_REDUCE(1, 9, tiles * 36, 256);
 #undef DEEPIPR_WGRAD_REDUCE
     return check_launch("conv_wgrad");
 }

@@ -114,7 +114,7 @@ def test_integration_stub_matches_the_abi():
     text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     lines = re.findall(r'^_L\.(deepipr_[a-z0-9_]+)\.argtypes = (.+)$', text, flags=re.M)
     assert {n for n, _ in lines} >= {'deepipr_pooled_patch_mean', 'deepipr_passport_fwd', 'deepipr_passport_bwd'}
-    env = {'_vp': ctypes.c_void_p, '_i': ctypes.c_int, '_f': ctypes.c_float}
+    env = {'_vp': ctypes.c_void_p, '_i': ctypes.c_int, '_f': ctypes.c_float, '_sz': ctypes.c_size_t}
     for name, expr in lines:
         stub = eval(expr, {'__builtins__': {}}, env)
         assert stub == _lib.SIGNATURES[name][1], name
@@ -130,10 +130,12 @@ def test_conv_wgrad_planner_and_argument_checks_without_a_gpu():
     ws = handle.deepipr_conv_wgrad_workspace_bytes
     assert ws(128, 64, 64, 32, 32, 3, 3, 1, 1) > 0 and ws(32, 512, 512, 4, 4, 3, 3, 1, 1) > 0
     assert ws(128, 64, 128, 32, 32, 3, 3, 2, 1) > 0 and ws(32, 256, 512, 8, 8, 3, 3, 2, 1) > 0           # stride 2
+    assert ws(128, 64, 128, 32, 32, 1, 1, 2, 0) > 0 and ws(128, 64, 128, 32, 32, 1, 1, 2, 1) == 0        # 1x1 stride 2 pad 0
     for bad in [(128, 3, 64, 32, 32, 3, 3, 1, 1), (128, 64, 64, 64, 64, 3, 3, 2, 1), (128, 64, 64, 32, 32, 3, 3, 3, 1), (128, 64, 64, 32, 32, 1, 1, 1, 0),
                 (128, 64, 64, 14, 14, 3, 3, 1, 1), (128, 64, 80, 8, 8, 3, 3, 1, 1), (3, 64, 64, 4, 4, 3, 3, 1, 1),
                 (0, 64, 64, 8, 8, 3, 3, 1, 1)]:
         assert ws(*bad) == 0, bad
     assert ws(128, 64, 64, 32, 32, 3, 3, 1, 1) % (64 * 64 * 9 * 4) == 0          # whole partial tiles
+    assert ws(128, 64, 128, 32, 32, 1, 1, 2, 0) % (64 * 64 * 4) == 0
     rc = handle.deepipr_conv_wgrad(None, None, None, 128, 64, 64, 32, 32, 3, 3, 1, 1, None, None, None, None, 0, None)
     assert rc == -1 and b'conv_wgrad' in handle.deepipr_last_error()

@@ -42,6 +42,9 @@ SHAPES = [
     # stride 2 (the first convolution of layer2 / 3 / 4): (N, Ci, Co, H, W of the INPUT, 2)
     (128, 64, 128, 32, 32, 2), (5, 64, 64, 32, 32, 2), (128, 128, 256, 16, 16, 2), (3, 128, 64, 16, 16, 2),
     (128, 256, 512, 8, 8, 2), (1, 256, 64, 8, 8, 2), (2, 64, 64, 16, 32, 2),
+    # 1x1 stride 2 pad 0 (the projection shortcuts): (N, Ci, Co, H, W of the INPUT, 2, 1)
+    (128, 64, 128, 32, 32, 2, 1), (3, 64, 64, 32, 32, 2, 1), (128, 128, 256, 16, 16, 2, 1), (5, 128, 64, 16, 16, 2, 1),
+    (128, 256, 512, 8, 8, 2, 1), (2, 256, 64, 8, 8, 2, 1), (32, 256, 512, 8, 8, 2, 1),
 ]
 
 
@@ -49,13 +52,15 @@ SHAPES = [
 def test_wgrad_matches_the_float64_oracle_and_is_bit_reproducible(K, shape):
     n, ci, co, h, w = shape[:5]
     st = shape[5] if len(shape) > 5 else 1
+    k = shape[6] if len(shape) > 6 else 3
+    pad = k // 2
     x, dy = _rand((n, ci, h, w), 1 + n + ci), _rand((n, co, h // st, w // st), 2 + n + co)
-    got = K.conv_wgrad(x, dy, (co, ci, 3, 3), st, 1)
-    assert got is not None and got.shape == (co, ci, 3, 3) and got.is_contiguous()
-    ref = _ref(x, dy, (co, ci, 3, 3), st)
+    got = K.conv_wgrad(x, dy, (co, ci, k, k), st, pad)
+    assert got is not None and got.shape == (co, ci, k, k) and got.is_contiguous()
+    ref = _ref(x, dy, (co, ci, k, k), st, pad)
     scale = float(ref.abs().max())
     assert float((got.double() - ref).abs().max()) <= 1e-5 * scale
-    again = K.conv_wgrad(x, dy, (co, ci, 3, 3), st, 1)
+    again = K.conv_wgrad(x, dy, (co, ci, k, k), st, pad)
     assert torch.equal(got, again)
 
 
@@ -75,6 +80,16 @@ def test_wgrad_sees_the_zero_padding_and_every_tap(K, st):
     ref = _ref(x, dy, (c, c, 3, 3), st)
     assert float(ref.abs().sum()) > 0
     assert torch.equal(got.double(), ref)                               # small integers: exact in fp32
+
+
+def test_rank2_term_fused_into_the_1x1_reduction_equals_the_separate_update(K):
+    n, ci, co, h = 8, 256, 512, 8
+    x, dy = _rand((n, ci, h, h), 5), _rand((n, co, h // 2, h // 2), 6)
+    dg, db = _rand((co,), 7), _rand((co,), 8)
+    m = torch.rand(2, ci, dtype=torch.float64, device=DEV) * 2 - 1
+    fused = K.conv_wgrad(x, dy, (co, ci, 1, 1), 2, 0, dg, db, m)
+    plain = K.conv_wgrad(x, dy, (co, ci, 1, 1), 2, 0)
+    assert torch.equal(fused, K.gamma_beta_bwd_acc(dg, db, m, plain.clone()))
 
 
 def test_rank2_term_fused_into_the_reduction_equals_the_separate_update(K):

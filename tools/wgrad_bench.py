@@ -18,7 +18,8 @@ from deepipr_amd.passport_ops import kernels as K      # noqa: E402
 
 # (Ci, Co, H = W of the input, stride): ResNet18's 3x3 convolutions
 SHAPES = [(64, 64, 32, 1), (128, 128, 16, 1), (256, 256, 8, 1), (512, 512, 4, 1),
-          (64, 128, 32, 2), (128, 256, 16, 2), (256, 512, 8, 2)]
+          (64, 128, 32, 2), (128, 256, 16, 2), (256, 512, 8, 2),
+          (64, 128, 32, 2, 1), (128, 256, 16, 2, 1), (256, 512, 8, 2, 1)]      # ... and its 1x1 stride-2 shortcuts
 
 
 def timeit(fn, reps):
@@ -44,17 +45,20 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_find
     dev = torch.device('cuda:0')
     out = []
-    for ci, co, hw, st in SHAPES:
+    for shape in SHAPES:
+        ci, co, hw, st = shape[:4]
+        k = shape[4] if len(shape) > 4 else 3
+        pad = k // 2
         n = args.batch
         g = torch.Generator(device='cpu').manual_seed(ci + hw)
         x = torch.randn(n, ci, hw, hw, generator=g).to(dev)
         dy = torch.randn(n, co, hw // st, hw // st, generator=g).to(dev)
-        w = torch.randn(co, ci, 3, 3, generator=g).to(dev)
-        ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [1, 1], [1, 1],
+        w = torch.randn(co, ci, k, k, generator=g).to(dev)
+        ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [pad, pad], [1, 1],
                                                   False, [0, 0], 1, [False, True, False])[1]
-        lib = lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1,
+        lib = lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1,
                                                           [False, True, False])[1]
-        mine = lambda: K.conv_wgrad(x, dy, w.shape, st, 1)
+        mine = lambda: K.conv_wgrad(x, dy, w.shape, st, pad)
         got = mine()
         assert got is not None, 'shape outside the kernel'
         torch.cuda.synchronize()
@@ -64,8 +68,8 @@ def main():
         again = mine()
         bit = bool(torch.equal(got, again))
         t_mine, t_lib = timeit(mine, args.reps), timeit(lib, args.reps)
-        flops = 2.0 * co * ci * 9 * n * (hw // st) ** 2
-        rec = {'Ci': ci, 'Co': co, 'HW': hw, 'stride': st, 'N': n, 'us': round(t_mine, 1), 'us_library': round(t_lib, 1),
+        flops = 2.0 * co * ci * k * k * n * (hw // st) ** 2
+        rec = {'Ci': ci, 'Co': co, 'HW': hw, 'k': k, 'stride': st, 'N': n, 'us': round(t_mine, 1), 'us_library': round(t_lib, 1),
                'TFLOPs': round(flops / t_mine / 1e6, 1), 'TFLOPs_library': round(flops / t_lib / 1e6, 1),
                'err_over_scale': err, 'err_library': err_lib, 'bit_reproducible': bit}
         print(json.dumps(rec), flush=True)
