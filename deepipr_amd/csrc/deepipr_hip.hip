@@ -4110,6 +4110,10 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
             case 116: launch_wgrad<WgCfg<1, 16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 108: launch_wgrad<WgCfg<1, 8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 104: launch_wgrad<WgCfg<1, 4, 4, 2>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 2132: launch_wgrad<WgCfg<1, 32, 4, 1, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 2116: launch_wgrad<WgCfg<1, 16, 8, 1, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 2108: launch_wgrad<WgCfg<1, 8, 8, 2, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 2104: launch_wgrad<WgCfg<1, 4, 4, 4, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 216: launch_wgrad<WgCfg<2, 16, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 208: launch_wgrad<WgCfg<2, 8, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 204: launch_wgrad<WgCfg<2, 4, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
@@ -4122,20 +4126,25 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     }
     const int tiles = p.tiles_co * p.tiles_ci;
     ProfScope prof(DEEPIPR_K_CONV_WGRAD_REDUCE, st);
-    prof.bytes = 4.0 * (static_cast<double>(p.splits) + 1.0) * tiles * 4096 * p.taps;
-#define DEEPIPR_WGRAD_REDUCE(SG, T, GRID, BLOCK)                                                                       \
+    prof.bytes = 4.0 * (static_cast<double>(p.splits) + 1.0) * tiles * 64 * p.cit * p.taps;
+#define DEEPIPR_WGRAD_REDUCE(SG, T, TW, GRID, BLOCK)                                                                   \
     do {                                                                                                              \
-        if (rank2) DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, true, T>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci, \
-                                  p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                     \
-        else DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, false, T>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,      \
+        if (rank2) DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, true, T, TW>), dim3(GRID), dim3(BLOCK), st, part, dW, \
+                                  Ci, p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                 \
+        else DEEPIPR_LAUNCH(prof, (k_conv_wgrad_reduce<SG, false, T, TW>), dim3(GRID), dim3(BLOCK), st, part, dW, Ci,  \
                             p.tiles_co, tiles, p.splits, dgamma, dbeta, m);                                           \
     } while (0)
+    // rows (64 lanes x 16 bytes) of a partial tile: 4 * tile waves * taps
     if (p.taps == 1) {
-        if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 1, tiles * 16, 256);
-        else DEEPIPR_WGRAD_REDUCE(1, 1, tiles * 4, 256);
-    } else if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, 9, tiles * 144, 1024);
-    else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 9, tiles * 144, 256);
-    else DEEPIPR_WGRAD_REDUCE(1, 9, tiles * 36, 256);
+        if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 1, 4, tiles * 16, 256);
+        else DEEPIPR_WGRAD_REDUCE(1, 1, 4, tiles * 4, 256);
+    } else if (p.cit == 32) {
+        if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, 9, 2, tiles * 72, 1024);
+        else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 9, 2, tiles * 72, 256);
+        else DEEPIPR_WGRAD_REDUCE(1, 9, 2, tiles * 18, 256);
+    } else if (p.splits >= 64) DEEPIPR_WGRAD_REDUCE(16, 9, 4, tiles * 144, 1024);
+    else if (p.splits >= 2) DEEPIPR_WGRAD_REDUCE(4, 9, 4, tiles * 144, 256);
+    else DEEPIPR_WGRAD_REDUCE(1, 9, 4, tiles * 36, 256);
 #undef DEEPIPR_WGRAD_REDUCE
     return check_launch("conv_wgrad");
 }
