@@ -877,11 +877,16 @@ def _own_ok(t, w):
 # leave CUs idle and the vendor library, shims included, is as fast or faster (tools/conv_bench.py at batch 128 and 32,
 # profiles/r04_conv_bench*.json).  The 1x1 stride-2 shortcuts always win (8-21 us against 26-46).
 OWN_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_MIN_POSITIONS', 4096))
+# ... and a stride-1 3x3 convolution from this many output positions up (ResNet18 at batch 128: layer1 and layer2, where the
+# direct kernel runs 78-82 us against Winograd's 88; 0 = never)
+OWN_S1_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_S1_MIN_POSITIONS', 32768))
 
 
 def _own_policy(n, h, w, k, stride):
     if OWN_CONV == 'all':
         return True
+    if stride == 1:
+        return k == 3 and OWN_S1_MIN_POSITIONS > 0 and n * h * w >= OWN_S1_MIN_POSITIONS
     if stride != 2:
         return False
     return k == 1 or n * (h // 2) * (w // 2) >= OWN_MIN_POSITIONS
