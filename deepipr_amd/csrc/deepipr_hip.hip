@@ -4099,6 +4099,19 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *part = static_cast<float *>(workspace);
     const int grid = p.splits * p.tiles_co * p.tiles_ci;
+    if (p.cfg == 3000) {                                                 // the stem (Ci = 3)
+        if (rank2) return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no fused rank-2 term for a 3-channel input");
+        {
+            ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
+            prof.bytes = 2.0 * Co * 27.0 * static_cast<double>(N) * H * W;
+            DEEPIPR_LAUNCH(prof, k_conv_stem_wgrad, dim3(grid), dim3(256), st, x, dy, part, Co, H, p.tiles_co, p.chunks,
+                           p.chunks_per_split);
+        }
+        ProfScope prof(DEEPIPR_K_CONV_WGRAD_REDUCE, st);
+        DEEPIPR_LAUNCH(prof, k_conv_stem_wgrad_reduce, dim3(Co), dim3(256), st, part, dW, Co, p.tiles_co,
+                       p.splits);
+        return check_launch("conv_wgrad");
+    }
     {
         ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
         prof.bytes = 2.0 * Co * Ci * p.taps * static_cast<double>(N) * (H / stride) * (W / stride);     // FLOPs, not bytes: this kernel's roofline is the MFMA peak

@@ -939,7 +939,10 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     if need_dw and _own_wgrad(x_in, w, stride, pad):
         dconv = dconv.contiguous()
         dx = _conv_dgrad(dconv, x_in, w, stride, pad) if need_dx else None
-        return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
+        if w.shape[1] % 64 == 0:
+            return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
+        # the 3-channel stem instance has no fused rank-2 term: the separate accumulate pass
+        return dx, kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad)), False
     own_dx = need_dx and _own_dgrad(x_in.shape, w, stride, pad, dconv)
     dx, dw, _ = torch.ops.aten.convolution_backward(
         dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,

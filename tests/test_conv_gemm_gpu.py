@@ -118,7 +118,7 @@ def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
         prof = _lib.profile_read()
         res[mode] = (y.detach(), x.grad, [p.grad for p in blk.parameters()],
                      tuple(int(prof[k][1]) for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad')))
-    assert res['all'][3] == (3, 3, 2) and res['auto'][3] == (2, 2, 2) and res['0'][3] == (0, 0, 0)
+    assert res['all'][3] == (3, 3, 3) and res['auto'][3] == (2, 2, 3) and res['0'][3] == (0, 0, 0)
     for mode in ('all', 'auto'):
         for a, b in zip([res[mode][0], res[mode][1]] + res[mode][2], [res['0'][0], res['0'][1]] + res['0'][2]):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9

@@ -45,6 +45,8 @@ SHAPES = [
     # 1x1 stride 2 pad 0 (the projection shortcuts): (N, Ci, Co, H, W of the INPUT, 2, 1)
     (128, 64, 128, 32, 32, 2, 1), (3, 64, 64, 32, 32, 2, 1), (128, 128, 256, 16, 16, 2, 1), (5, 128, 64, 16, 16, 2, 1),
     (128, 256, 512, 8, 8, 2, 1), (2, 256, 64, 8, 8, 2, 1), (32, 256, 512, 8, 8, 2, 1),
+    # the stem: 3 input channels, (ci, tap) = 27 columns of one accumulator tile
+    (128, 3, 64, 32, 32), (5, 3, 64, 32, 32), (32, 3, 128, 32, 32), (2, 3, 64, 8, 32),
 ]
 
 
@@ -105,7 +107,7 @@ def test_rank2_term_fused_into_the_reduction_equals_the_separate_update(K):
 
 
 @pytest.mark.parametrize('case', [
-    dict(n=4, ci=3, co=64, h=32, w=32), dict(n=4, ci=64, co=64, h=14, w=14), dict(n=4, ci=64, co=96, h=8, w=8),
+    dict(n=4, ci=3, co=64, h=16, w=16), dict(n=4, ci=4, co=64, h=32, w=32), dict(n=4, ci=64, co=64, h=14, w=14), dict(n=4, ci=64, co=96, h=8, w=8),
     dict(n=4, ci=64, co=64, h=8, w=8, k=1, pad=0), dict(n=4, ci=64, co=64, h=64, w=64, stride=2),
     dict(n=4, ci=64, co=64, h=8, w=8, stride=3),
     dict(n=3, ci=64, co=64, h=4, w=4)])

@@ -210,15 +210,18 @@ def test_gamma_beta_multi_matches_the_oracle_and_the_single_layer_calls(K, batch
 
 
 # ----------------------------------------------------------------------------- rank-2 update of a layer group in one launch
+@pytest.mark.parametrize('own_wgrad', [True, False])
 @pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2', 'resnet18_v2_private_pass_first', 'alexnet_v1'])
-def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_kind, monkeypatch):
+def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_kind, own_wgrad, monkeypatch):
     """The passport branch's dW of a group of layers in ONE launch (_Rank2Group, the default) against one launch per
     layer (DEEPIPR_NO_RANK2_BATCH=1) and against no batching at all (DEEPIPR_NO_GEMV_BATCH=1): logits and every
     parameter gradient bit-identical with MIOpen pinned; the launch counts say which form ran.  The AlexNet's passport
     layers span two backward stages (features 4 | 5, 6): the groups follow the stages."""
     from deepipr_amd import _lib
+    from deepipr_amd import passport_ops as P
     from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
     from oracle.cases import alexnet_config, resnet18_config
+    monkeypatch.setattr(P, 'OWN_WGRAD', own_wgrad)            # False: the vendor library's wgrad + the separate rank-2 update
     private = 'v2' in net_kind
     rev = net_kind.endswith('first')     # the private pass's nodes are then the OLDER ones: the other backward order
     if net_kind.startswith('resnet18'):
@@ -276,8 +279,8 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
     n_layers = 3 if net_kind == 'alexnet_v1' else 5
     fwd_passes = 1                                              # V2: only the private pass (ind = 1) uses the passports
     # layers whose weight gradient deepipr_conv_wgrad computes get their rank-2 term in ITS reduction pass (no launch of
-    # their own, grouped or not); the others -- ResNet18: the 1x1 shortcut of layer4.0 -- keep the separate update
-    from deepipr_amd import passport_ops as P
+    # their own, grouped or not) -- since the 1x1 stride-2 instance all passport layers of both nets; a layer outside the
+    # kernel (other geometry, DEEPIPR_OWN_WGRAD=0) keeps the separate update, one launch per group or per layer
     from deepipr_amd.models._builders import PASSPORT_TYPES
     shape = {}
     hooks = [m.register_forward_pre_hook(lambda mod, inp: shape.__setitem__(mod, inp[0].shape))
@@ -289,11 +292,13 @@ def test_grouped_rank2_update_is_bit_identical_to_the_per_layer_updates(K, net_k
     net.load_state_dict(state)
     separate = [m for m, shp in shape.items()
                 if not P._own_wgrad(torch.empty(shp, device=DEV), m.weight, m.conv.stride[0], m.conv.padding[0])]
-    assert len(shape) == n_layers and len(separate) == (0 if net_kind == 'alexnet_v1' else 1)
+    assert len(shape) == n_layers and len(separate) == (0 if own_wgrad else n_layers)
     assert (f1, b1) == (fwd_passes, len(separate) * fwd_passes), (f1, b1)
     assert (f2, b2) == (n_layers * fwd_passes, len(separate) * fwd_passes), (f2, b2)
-    # one launch per group that still has such a layer
-    assert (f0, b0) == (fwd_passes, 1 if separate else 0), (f0, b0)
+    # one launch per group that still has such layers: ResNet18's five layers are one stage; AlexNet: features 5, 6
+    # together, features 4 alone
+    groups = 0 if own_wgrad else (2 if net_kind == 'alexnet_v1' else 1)
+    assert (f0, b0) == (fwd_passes, groups), (f0, b0)
     for name, other in (('per layer', per_layer), ('unbatched', unbatched)):
         assert set(other) == set(grouped)
         diff = {k: float((grouped[k] - other[k]).abs().max()) for k in grouped if not torch.equal(grouped[k], other[k])}

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepipr_amd.passport_ops import kernels as K      # noqa: E402
 
 # (Ci, Co, H = W of the input, stride): ResNet18's 3x3 convolutions
-SHAPES = [(64, 64, 32, 1), (128, 128, 16, 1), (256, 256, 8, 1), (512, 512, 4, 1),
+SHAPES = [(3, 64, 32, 1), (64, 64, 32, 1), (128, 128, 16, 1), (256, 256, 8, 1), (512, 512, 4, 1),
           (64, 128, 32, 2), (128, 256, 16, 2), (256, 512, 8, 2),
           (64, 128, 32, 2, 1), (128, 256, 16, 2, 1), (256, 512, 8, 2, 1)]      # ... and its 1x1 stride-2 shortcuts
 
