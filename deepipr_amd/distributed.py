@@ -114,7 +114,7 @@ def ranks_seen(device):
     bench.py reports it next to WORLD_SIZE, which only says what the launcher promised."""
     if not dist.is_initialized():
         return 1
-    t = torch.ones(1, dtype=torch.float32, device=device)
+    t = torch.ones(1, dtype=torch.float32, device='cpu' if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(round(float(t.item())))
 
@@ -161,6 +161,8 @@ def gradients_agree(grads, device):
         bits = bits + g.view(torch.int32).to(torch.int64).sum()
         sums.append(torch.stack([g.double().sum(), g.double().abs().sum()]))
     vec = torch.cat([bits.to(torch.float64).reshape(1)] + sums) if sums else bits.to(torch.float64).reshape(1)
+    if dist.get_backend() == 'gloo':                        # gloo gathers host tensors (two small vectors)
+        vec, bits = vec.cpu(), bits.cpu()
     world = dist.get_world_size()
     gathered = [torch.zeros_like(vec) for _ in range(world)]
     dist.all_gather(gathered, vec)

@@ -136,6 +136,7 @@ class StepRunner:
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         self._graphed = None
         self._shape = None
+        self._probe = None                 # staged data-parallel step: (replays left to watch, state to fall back to)
 
     def _build(self, data, target):
         if self.distributed and hasattr(self.optimizer, 'configure_stages') and hasattr(self.step_fn, 'forward_loss'):
@@ -151,9 +152,43 @@ class StepRunner:
         if self._graphed is None:
             self._graphed = self._build(data, target)
             self._shape = (tuple(data.shape), tuple(target.shape))
-            return self._graphed(data, target)          # capture does not execute: replay the first batch
+            if self.distributed and hasattr(self._graphed, 'describe') and hasattr(self.optimizer, 'flat_buf'):
+                # The staged step lets collectives overlap the split-channel single-pass kernels (policy "shared",
+                # staged.py); should their in-launch exchange ever time out next to one, the first replays show it.
+                # Watch them, all ranks together, instead of finding NaN statistics at the end of the epoch.
+                self._probe = [3, {k: v.clone() for k, v in self.model.state_dict().items()}, self.optimizer.flat_buf.clone()]
+            return self._watched(self._graphed(data, target), data, target)      # capture does not execute: replay the first batch
         if (tuple(data.shape), tuple(target.shape)) != self._shape:
             return self.step_fn(self.model, self.optimizer, data, target)
+        return self._watched(self._graphed(data, target), data, target)
+
+    def _watched(self, out, data, target):
+        if self._probe is None:
+            return out
+        self._probe[0] -= 1
+        if self._probe[0] > 0:
+            return out
+        from deepipr_amd import passport_ops
+        kernels = passport_ops.kernels
+        if data.is_cuda:
+            torch.cuda.synchronize()
+        ok = torch.tensor([0.0 if kernels.sync_timeouts() else 1.0], device=data.device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)       # every rank takes the same form
+        _n, state, flat = self._probe
+        self._probe = None
+        if float(ok.item()) > 0.5:
+            return out
+        print('deepipr_amd: an in-launch exchange of the single-pass norm kernels timed out next to a collective on some '
+              'rank; all ranks fall back to the three-launch form for the split-channel layers, restore the state of three '
+              'steps ago and capture the step again', flush=True)
+        kernels.set_user_sync(False)
+        kernels.reset_sync_words()
+        if hasattr(self._graphed, 'close'):
+            self._graphed.close()
+        with torch.no_grad():
+            self.model.load_state_dict(state)
+            self.optimizer.flat_buf.copy_(flat)
+        self._graphed = self._build(data, target)
         return self._graphed(data, target)
 
 

@@ -8,6 +8,7 @@ Checked: (1) replicas start identical to rank 0 (weights, keys, signature bits) 
 built with a different seed; (2) one data-parallel step on two half-batches equals one single-process step
 on the full batch (norm_type='none', so no per-shard batch statistics enter); (3) ranks stay in lock step.
 """
+import json
 import os
 import socket
 import sys
@@ -282,3 +283,74 @@ def test_find_phase_helpers_without_a_process_group():
     res, _s = D.rank0_first(lambda: 7)
     assert res == 7 and D.ranks_seen(torch.device('cpu')) == 1
     assert D.gradients_agree([torch.ones(2)], torch.device('cpu')) == (None, None)
+
+
+def _runner_fallback_worker(rank, world, port, out_dir):
+    """StepRunner's watch over the first staged replays: ONE rank sees an exchange time-out, BOTH must fall back."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from deepipr_amd import distributed as D
+    from deepipr_amd import passport_ops
+    from deepipr_amd.experiments.trainer import StepRunner
+    D.init_from_env('gloo')
+
+    class FakeKernels:
+        def __init__(self):
+            self.calls = []
+        def sync_timeouts(self):
+            return 1 if rank == 1 else 0
+        def set_user_sync(self, on):
+            self.calls.append(('set_user_sync', on))
+        def reset_sync_words(self):
+            self.calls.append(('reset_sync_words',))
+
+    class FakeStep:
+        built = 0
+        def __init__(self):
+            FakeStep.built += 1
+            self.closed = False
+        def __call__(self, data, target):
+            with torch.no_grad():
+                model.weight.add_(1.0)
+                opt.flat_buf.add_(1.0)
+            return {'loss': 0.0}
+        def describe(self):
+            return ''
+        def close(self):
+            self.closed = True
+
+    class FakeOpt:
+        flat_buf = torch.zeros(4)
+
+    fake = FakeKernels()
+    real = passport_ops.kernels
+    passport_ops.kernels = fake
+    try:
+        model, opt = torch.nn.Linear(2, 2), FakeOpt()
+        w0 = model.weight.detach().clone()
+        run = StepRunner(lambda *a: None, model, opt, graph=True)
+        run._build = lambda d, t: FakeStep()
+        first = run._graphed = run._build(None, None)
+        run._probe = [3, {k: v.clone() for k, v in model.state_dict().items()}, opt.flat_buf.clone()]
+        x = torch.zeros(1)
+        for _ in range(3):
+            run._watched(run._graphed(x, x), x, x)
+        report = {'calls': fake.calls, 'built': FakeStep.built, 'first_closed': first.closed, 'probe': run._probe,
+                  'weight_steps': float((model.weight.detach() - w0).mean()), 'buf': float(opt.flat_buf.mean())}
+        with open(os.path.join(out_dir, f'runner{rank}.json'), 'w') as f:
+            json.dump(report, f)
+    finally:
+        passport_ops.kernels = real
+        torch.distributed.destroy_process_group()
+
+
+def test_step_runner_falls_back_on_every_rank_when_one_rank_saw_an_exchange_timeout(tmp_path):
+    """the trainer path (not only bench.py) watches the staged step's first replays and, by a MIN all-reduce,
+    takes every rank to the three-launch form together, restoring the state the watched replays started from."""
+    mp.spawn(_runner_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        r = json.load(open(tmp_path / f'runner{rank}.json'))
+        assert r['calls'] == [['set_user_sync', False], ['reset_sync_words']], r
+        assert r['built'] == 2 and r['first_closed'] and r['probe'] is None
+        # three watched replays undone, one replay of the rebuilt step
+        assert r['weight_steps'] == pytest.approx(1.0) and r['buf'] == pytest.approx(1.0)
