@@ -380,13 +380,27 @@ def main():
         probe['grads'] = torch.autograd.grad(objective, params, allow_unused=True)
     keep0 = {k: v.clone() for k, v in model.state_dict().items()} if many else None
     (all_elems, elems), find_s = D.rank0_first(lambda: fused_layer_elements(model, find_pass), device)
-    agree, agree_tol = D.gradients_agree(probe.pop('grads'), device)
+    agree, agree_tol = D.gradients_agree(probe['grads'], device)
+    agree_detail = dict(D.LAST_AGREEMENT) or None
+    # the yardstick for the line above: the SAME rank running the same pass twice (vendor kernels that accumulate with
+    # atomics make even that differ in the low bits; this library's kernels do not)
+    repeat = None
+    if many:
+        first = D.gradient_digest(probe.pop('grads'), device)
+        find_pass()
+        torch.cuda.synchronize()
+        again = D.gradient_digest(probe.pop('grads'), device)
+        rb, rc, rd = D.digests_agree(first, again)
+        repeat = {'bitwise': rb, 'weights_1e-5': rc, **rd}
+    probe.clear()
     if keep0 is not None:                                  # every rank back on the broadcast state (norm statistics moved)
         with torch.no_grad():
             model.load_state_dict(keep0)
     del probe_x, probe_y, keep0
-    note('find phase done in %.1f s (rank 0 first): MIOpen solver selection for every conv shape; ranks agree: %s'
-         % (find_s, agree))
+    find_timeouts = _exchange_timeouts() or 0
+    note('find phase done in %.1f s (rank 0 first): MIOpen solver selection for every conv shape; ranks agree: %s %s; '
+         'this rank against itself: %s; exchange time-outs on this rank during it: %d'
+         % (find_s, agree, agree_detail or '', repeat, find_timeouts))
     # Launch mode of the timed region: hipGraph replay by default.  The step issues ~260 dispatches (~500 for the
     # dual-forward V2/V3 step); eager enqueue costs 4.5-9 ms of host time against 5.1-5.6 ms of GPU time, so an eager
     # step is host-bound exactly where it matters most (32 images per GPU in config P).
@@ -559,7 +573,8 @@ def main():
         'rccl_ranks_seen': ranks_seen,                     # measured by a collective, not read from the environment
         # after the find phase every rank ran the same forward + backward (rank 0's batch, broadcast weights): identical
         # gradients bit for bit / within 1e-5 of scale (None on one GPU)
-        'ranks_agree_bitwise': agree, 'ranks_agree_1e-5': agree_tol, 'find_phase_s': round(find_s, 1),
+        'ranks_agree_bitwise': agree, 'ranks_agree_1e-5': agree_tol, 'ranks_agree_detail': agree_detail, 'same_rank_repeat_agrees': repeat,
+        'find_phase_exchange_timeouts': find_timeouts, 'find_phase_s': round(find_s, 1),
         'exchange_us_exposed': None if exposed_us is None else round(exposed_us, 1),
         'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '
                                 '%d classes, 3x%dx%d, batch %d/GPU, SGD(0.01,0.9,wd1e-4)' %

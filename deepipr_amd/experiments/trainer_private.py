@@ -22,7 +22,9 @@ class DualBranch(nn.Module):
     """model(x, ind=0) and model(x, ind=1) in one forward call, public branch first so that the batch-norm
     running statistics are updated in the reference's order.  Nets that offer forward_dual run the layers in front of
     their first private passport layer once for both branches (models/_builders.shared_trunk: same outputs, same
-    gradients, same running statistics; DEEPIPR_NO_SHARED_TRUNK=1 restores the two full passes)."""
+    gradients, same running statistics; DEEPIPR_NO_SHARED_TRUNK=1 restores the two full passes).  A net that carries
+    hooks the one-pass form would not fire as two calls do -- forward pre-hooks, backward (pre-)hooks, global hooks, or
+    any hook on a submodule (feature collectors of the attack / fine-tune scripts) -- takes the two full passes."""
 
     def __init__(self, model):
         super().__init__()
@@ -31,8 +33,9 @@ class DualBranch(nn.Module):
     def forward(self, data):
         m = self.model
         from torch.nn.modules import module as _mod
-        if (not hasattr(m, 'forward_dual') or m._forward_pre_hooks or _mod._global_forward_hooks
-                or _mod._global_forward_pre_hooks):
+        if (not hasattr(m, 'forward_dual') or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks
+                or _mod._global_forward_hooks or _mod._global_forward_pre_hooks or _mod._global_backward_hooks
+                or _mod._global_backward_pre_hooks or _submodule_hooks(m)):
             return m(data, ind=0), m(data, ind=1)
         outs = list(m.forward_dual(data))
         # the net's own forward hooks see two calls, as with model(data, ind=0); model(data, ind=1)
@@ -46,6 +49,15 @@ class DualBranch(nn.Module):
                     out = res
             outs[ind] = out
         return outs[0], outs[1]
+
+
+def _submodule_hooks(model):
+    """Any hook on a module below the net itself (the net's own forward hooks are re-fired by DualBranch)."""
+    for sub in model.modules():
+        if sub is not model and (sub._forward_hooks or sub._forward_pre_hooks or sub._backward_hooks
+                                 or sub._backward_pre_hooks):
+            return True
+    return False
 
 
 def _unwrap(model):

@@ -11,6 +11,7 @@ Reference lines each operator stands in for (paths relative to kamwoh/DeepIPR):
   passport_layer      all of the above in two launches forward, two backward
 """
 import os
+import weakref
 
 import torch
 
@@ -1003,7 +1004,7 @@ def conv2d(conv, x):
             and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
             and conv.kernel_size[0] == conv.kernel_size[1]
             and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or conv._backward_pre_hooks)
-            and type(conv) is torch.nn.Conv2d):
+            and type(conv) is torch.nn.Conv2d and 'forward' not in conv.__dict__):     # nor wrapped its forward
         st, pd, w = conv.stride[0], conv.padding[0], conv.weight
         if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)):
             return _Conv2dOwn.apply(x, w, st, pd)
@@ -1330,19 +1331,37 @@ class gamma_beta_batch:
         return False
 
 
+_STAGE_TABLES = weakref.WeakKeyDictionary()      # model -> {submodule: backward stage}; nothing lands in the model's state
+
+
 def stage_groups(model):
     """layer -> index of the backward stage (model.backward_stages()) it belongs to: the `group_of` of
-    gamma_beta_batch.  Cached on the model."""
-    cached = model.__dict__.get('_stage_of')
-    table = cached[1] if (cached is not None and cached[0] == id(model)) else None     # a deep copy carries stale ids
-    if table is None:
-        table = {}
+    gamma_beta_batch.  Cached per model, keyed on the module objects themselves (weakly): a layer swapped in after the
+    first forward (fine-tune / attack scripts) misses the table and has it rebuilt rather than landing in stage -1, and
+    a recycled id() cannot file a layer under another layer's stage; a deep copy of the model starts
+    without a table."""
+    table = _STAGE_TABLES.get(model)
+
+    def build():
+        fresh = weakref.WeakKeyDictionary()
         for k, (_cut, mods) in enumerate(model.backward_stages()):
             for mod in mods:
                 for sub in mod.modules():
-                    table.setdefault(id(sub), k)
-        model.__dict__['_stage_of'] = (id(model), table)
-    return lambda layer: table.get(id(layer), -1)
+                    fresh.setdefault(sub, k)
+        _STAGE_TABLES[model] = fresh
+        return fresh
+
+    if table is None:
+        table = build()
+    state = {'table': table, 'rebuilt': False}
+
+    def group_of(layer):
+        k = state['table'].get(layer)
+        if k is None and not state['rebuilt']:
+            state['table'], state['rebuilt'] = build(), True
+            k = state['table'].get(layer)
+        return -1 if k is None else k
+    return group_of
 
 
 def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False):

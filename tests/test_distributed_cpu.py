@@ -258,8 +258,13 @@ def _find_phase_worker(rank, world, port, out_dir):
     agree_diff = D.gradients_agree(diff, dev)
     near = [torch.arange(1.0, 7.0).view(2, 3) * (1.0 + (1e-7 if rank else 0.0)), torch.ones(4)]
     agree_near = D.gradients_agree(near, dev)
+    # a norm layer's shift gradient (1-D, a sum that cancels): reported in LAST_AGREEMENT, not judged
+    shift = [torch.arange(6.0).view(2, 3), torch.tensor([1.0, -1.0 + (1e-3 if rank else 0.0)])]
+    agree_shift = D.gradients_agree(shift, dev)
+    detail_shift = dict(D.LAST_AGREEMENT)
     torch.save(dict(res=res, seconds=seconds, seen=seen, agree_same=agree_same, agree_diff=agree_diff,
-                    agree_near=agree_near), os.path.join(out_dir, 'r%d.pt' % rank))
+                    agree_near=agree_near, agree_shift=agree_shift, detail_shift=detail_shift),
+               os.path.join(out_dir, 'r%d.pt' % rank))
     D.shutdown()
 
 
@@ -275,6 +280,8 @@ def test_find_phase_helpers_rank0_first_then_the_others(tmp_path):
     assert r0['agree_same'] == r1['agree_same'] == (True, True)
     assert r0['agree_diff'] == r1['agree_diff'] == (False, False)
     assert r0['agree_near'] == r1['agree_near'] == (False, True)          # not the same bits, the same to rounding
+    assert r0['agree_shift'] == r1['agree_shift'] == (False, True)
+    assert r0['detail_shift']['worst_rel_1d'] > 1e-4 and r0['detail_shift']['worst_rel_weights'] == 0.0
     assert r1['seconds'] >= 0.4                                           # rank 1 waited for rank 0
 
 

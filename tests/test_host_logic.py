@@ -614,9 +614,11 @@ def test_shared_trunk_of_the_dual_forward_equals_two_full_passes(arch, cpu_kerne
         opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
         calls = {'n': 0}
         stem_conv = net.convbnrelu_1.conv if arch == 'resnet18' else net.features[0].conv
-        stem_conv.register_forward_hook(lambda *_a: calls.__setitem__('n', calls['n'] + 1))
+        # counted by wrapping .forward: a hook on a submodule makes DualBranch take the two full passes, and
+        # a module hook would make the layer keep its convolution to itself
+        stem_inner = stem_conv.forward
+        stem_conv.forward = lambda inp, _f=stem_inner: (calls.__setitem__('n', calls['n'] + 1), _f(inp))[1]
         # the first private layer behind the split: its data convolution is shared by the two branches as well
-        # (counted by wrapping .forward: a module hook would make the layer keep its convolution to itself)
         first = (net.layer4[0].convbnrelu_1 if arch == 'resnet18' else net.features[4]).conv
         inner = first.forward
         first.forward = lambda inp, _f=inner: (calls.__setitem__('first', calls.get('first', 0) + 1), _f(inp))[1]
@@ -679,3 +681,63 @@ def test_alexnet_split_at_the_stage_cut_does_not_share_the_convolution(cpu_kerne
     net.load_state_dict(state)
     b0, b1 = net(x, ind=0), net(x, ind=1)
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_stage_groups_follow_layers_swapped_in_after_the_first_lookup(cpu_kernels):
+    """the layer -> backward-stage table is keyed on the module objects; a block replaced after the first
+    forward (fine-tune / attack scripts) is filed under its real stage, not -1, and nothing is kept in the model."""
+    import copy
+    from deepipr_amd import passport_ops as P
+    from deepipr_amd.models.resnet_passport import ResNet18Passport
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from oracle.cases import resnet18_config
+    torch.manual_seed(0)
+    kw = construct_passport_kwargs_from_dict({'passport_config': resnet18_config(), 'norm_type': 'bn',
+                                              'key_type': 'random', 'sl_ratio': 0.1})
+    net = ResNet18Passport(num_classes=10, passport_kwargs=kw)
+    stages = net.backward_stages()
+    group_of = P.stage_groups(net)
+    last = stages[-1][1][-1]
+    inner = next(m for m in last.modules() if m is not last)
+    k = group_of(inner)
+    assert k == len(stages) - 1 and group_of(torch.nn.ReLU()) == -1
+    # swap a submodule of that stage for a fresh object
+    name, old = next((n, m) for n, m in last.named_children())
+    fresh = copy.deepcopy(old)
+    setattr(last, name, fresh)
+    assert P.stage_groups(net)(fresh) == k
+    assert '_stage_of' not in net.__dict__
+    clone = copy.deepcopy(net)
+    assert P.stage_groups(clone)(next(m for m in clone.backward_stages()[0][1][0].modules())) == 0
+
+
+def test_dual_branch_takes_two_full_passes_when_a_submodule_carries_a_hook(cpu_kernels):
+    """hooks the one-pass form would fire once (or never) force model(x, ind=0); model(x, ind=1)."""
+    from deepipr_amd.experiments.trainer_private import DualBranch, _submodule_hooks
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = torch.nn.Linear(3, 3)
+            self.calls = []
+        def forward(self, x, ind=0):
+            self.calls.append(('forward', ind))
+            return self.trunk(x) + ind
+        def forward_dual(self, x):
+            self.calls.append(('dual',))
+            t = self.trunk(x)
+            return t, t + 1
+
+    net, x = Net(), torch.zeros(2, 3)
+    DualBranch(net)(x)
+    assert net.calls == [('dual',)] and not _submodule_hooks(net)
+    seen = []
+    handle = net.trunk.register_forward_hook(lambda m, i, o: seen.append(1))
+    net.calls.clear()
+    DualBranch(net)(x)
+    assert net.calls == [('forward', 0), ('forward', 1)] and len(seen) == 2
+    handle.remove()
+    net.register_full_backward_hook(lambda m, gi, go: None)
+    net.calls.clear()
+    DualBranch(net)(x)
+    assert net.calls == [('forward', 0), ('forward', 1)]
