@@ -94,6 +94,8 @@ SIGNATURES = {
     'deepipr_conv_supported': (_int, [_int] * 9),
     'deepipr_conv_fwd': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp]),
     'deepipr_conv_dgrad': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp]),
+    'deepipr_conv_set_arith': (_int, [_int]),
+    'deepipr_conv_get_arith': (_int, []),
     'deepipr_conv_wgrad_workspace_bytes': (_sz, [_int] * 9),
     'deepipr_conv_wgrad': (_int, [_f32p, _f32p, _f32p] + [_int] * 9 + [_f32p, _f32p, _f64p, _vp, _sz, _vp]),
 }
@@ -102,7 +104,7 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_debug_trace': (_int, [_vp]),
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 

@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -4076,9 +4077,33 @@ void launch_wgrad(ProfScope &prof, const WgradPlan &p, const float *x, const flo
     DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad<C>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H, p.tiles_co, p.tiles_ci,
                    p.chunks, p.chunks_per_split);
 }
+
+template <class C>
+void launch_wgrad_b3(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
+                     hipStream_t st) {
+    const int grid = p.splits * p.tiles_co * p.tiles_ci;
+    static const int dbg = getenv("DEEPIPR_B3_DBG") ? atoi(getenv("DEEPIPR_B3_DBG")) : 0;
+#define B3_DBG(D)                                                                                                    \
+    case D:                                                                                                          \
+        DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad_b3<C, D>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H,     \
+                       p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split);                                        \
+        return;
+    switch (dbg) { B3_DBG(1) B3_DBG(6) B3_DBG(16) B3_DBG(17) B3_DBG(22) default: break; }
+#undef B3_DBG
+    DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad_b3<C>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H, p.tiles_co,
+                   p.tiles_ci, p.chunks, p.chunks_per_split);
+}
 }  // namespace
 
 extern "C" {
+
+int deepipr_conv_set_arith(int mode) {
+    if (mode != 0 && mode != 1) return fail(DEEPIPR_EINVAL, "conv_set_arith: 0 (fp32 MFMA) or 1 (bf16x3)");
+    g_conv_arith = mode;
+    return DEEPIPR_OK;
+}
+
+int deepipr_conv_get_arith(void) { return conv_arith(); }
 
 size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, int kh, int kw, int stride, int pad) {
     return plan_wgrad(N, Ci, Co, H, W, kh, kw, stride, pad).workspace;
@@ -4127,6 +4152,9 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
             case 2116: launch_wgrad<WgCfg<1, 16, 8, 1, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 2108: launch_wgrad<WgCfg<1, 8, 8, 2, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 2104: launch_wgrad<WgCfg<1, 4, 4, 4, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 4032: launch_wgrad_b3<WbCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 4016: launch_wgrad_b3<WbCfg<16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+            case 4008: launch_wgrad_b3<WbCfg<8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 216: launch_wgrad<WgCfg<2, 16, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 208: launch_wgrad<WgCfg<2, 8, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 204: launch_wgrad<WgCfg<2, 4, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;

@@ -657,6 +657,18 @@ class HipKernels:
             v = self._wgrad_ws[key] = int(_lib.lib().deepipr_conv_wgrad_workspace_bytes(*key))
         return v
 
+    def set_conv_arith(self, mode):
+        """'bf16x3' (default: fp32 operands split exactly into three bf16 words, six products on the bf16 matrix cores,
+        fp32 accumulation -- one fp32 rounding per product) or 'fp32' (the fp32 MFMA) for the 3x3 stride-1 weight
+        gradients; process-wide (deepipr_conv_set_arith).  -> the previous mode."""
+        before = self.conv_arith()
+        _lib.check(_lib.lib().deepipr_conv_set_arith({'fp32': 0, 'bf16x3': 1}[mode]), 'conv_set_arith')
+        self._wgrad_ws.clear()
+        return before
+
+    def conv_arith(self):
+        return ('fp32', 'bf16x3')[_lib.lib().deepipr_conv_get_arith()]
+
     def conv_wgrad(self, x, dy, wshape, stride, pad, dgamma=None, dbeta=None, m=None):
         """dW of conv(x, W) for upstream gradient dy, or None when the shape is outside the kernel.  With dgamma /
         dbeta / m the passport branch's rank-2 term is added in the same pass (deepipr_gamma_beta_bwd_acc's result)."""

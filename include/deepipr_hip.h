@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 7
+#define DEEPIPR_ABI_VERSION 8
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -424,7 +424,17 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
  * replaces: the weight half of aten::convolution_backward behind `self.conv(x)`,
  *           models/layers/passportconv2d.py:218 (private twin :215), models/layers/conv2d.py:31 -- MIOpen's
  *           igemm_wrw_gtcx35_nhwc + batched_transpose_* + SubTensorOpWithScalar1d (profiles/r03_steady_state.md).
- * x [N][Ci][H][W]   dy [N][Co][H][W]   dW [Co][Ci][3][3]   m [2][Ci*9] double   all pointers 16-byte aligned */
+ * x [N][Ci][H][W]   dy [N][Co][H][W]   dW [Co][Ci][3][3]   m [2][Ci*9] double   all pointers 16-byte aligned
+ *
+ * Arithmetic (ABI v8).  The 3x3 stride-1 instances on maps 8 / 16 / 32 wide run, by default, on the bf16 matrix cores
+ * with every fp32 operand split EXACTLY into three bf16 words (x = h + m + l) and six of the nine cross products
+ * accumulated in fp32 ("bf16x3": v_mfma_f32_32x32x16_bf16 multiplies at 16x the rate of the fp32 MFMA; the three products
+ * left out are below 2^-24 |x y|, so a product carries the error of ONE fp32 rounding; still a fixed summation order,
+ * still bit-reproducible; one-hot inputs still give exact results).  deepipr_conv_set_arith(0) -- or DEEPIPR_CONV_ARITH=fp32
+ * in the environment at load time -- restores the fp32 MFMA for those shapes; deepipr_conv_get_arith reports the mode.
+ * The setting is process-wide and read when a call is planned: do not change it between a workspace query and its call. */
+int deepipr_conv_set_arith(int mode);          /* 0: fp32 MFMA, 1: bf16x3 */
+int deepipr_conv_get_arith(void);
 size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, int kh, int kw, int stride, int pad);
 int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci, int Co, int H, int W, int kh, int kw,
                        int stride, int pad, const float *dgamma, const float *dbeta, const double *m, void *workspace,
