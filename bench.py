@@ -39,6 +39,7 @@ from deepipr_amd.models.resnet_passport import ResNet18Passport                 
 from deepipr_amd.models.resnet_passport_private import ResNet18Private             # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16), 16x the fp32 one
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32, = the vector rate)
 # algorithmic bytes per activation element are accounted by the library per timed
 # launch: single-pass norm+affine+ReLU 8 forward / 12 backward; 3-launch form: stats 4, apply 8, backward sums 8,
@@ -72,6 +73,14 @@ def build_model(args, device):
     else:
         model = ResNet18Private(num_classes=args.classes, passport_kwargs=kw, imagenet=getattr(args, 'image_size', 32) > 32)
     return model.to(device)
+
+
+def _conv_arith():
+    try:
+        from deepipr_amd.passport_ops import kernels
+        return kernels.conv_arith()
+    except Exception:
+        return None
 
 
 def _exchange_timeouts():
@@ -565,7 +574,8 @@ def main():
         'value': round(value, 1), 'unit': 'img/s',
         'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32' if _conv_arith() != 'bf16x3' else 'f32 (3x3 stride-1 weight gradients: bf16x3 products, f32 accumulate)',
+        'data': 'synthetic',
         'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
         # bounded in-kernel waits of the single-pass kernels' partial-sum exchange that ever expired (must be 0)
         'exchange_timeouts': _exchange_timeouts(),
@@ -584,6 +594,11 @@ def main():
                                     '' if args.norm_type == 'bn' else ', norm_type ' + args.norm_type) + (
                                     ', library norm kernels (--no-fuse)' if args.no_fuse else ''),
                    'global_batch': args.gpus * args.batch, 'parallelism': 'dp%d' % args.gpus,
+                   # 'fp32' (default): fp32 operands, fp32 MFMA, fp32 results everywhere.  'bf16x3' (DEEPIPR_CONV_ARITH=bf16x3,
+                   # opt-in): the 3x3 stride-1 weight gradients multiply on the bf16 matrix cores with each fp32 operand split
+                   # EXACTLY into three bf16 words and six of the nine products kept -- one fp32 rounding per product, as
+                   # accurate against float64 as the fp32 MFMA kernel (profiles/r04_wgrad_bench_bf16x3.json)
+                   'conv_arithmetic': _conv_arith(),
                    'optimizer': 'DDP+torch fused SGD' if args.ddp else 'FlatSGD (flat buffers; RCCL all-reduce of the gradient buckets between the replayed backward stages, or from gradient hooks with --eager)',
                    'exchange': stage_plan,
                    'passport_layers': len(elems), 'fused_norm_layers': len(all_elems),
@@ -652,28 +667,48 @@ def main():
                        'layer calls of %.1f MB among them); bytes and time summed over the timed '
                        'launches' % (len(all_elems), 4 * min(all_elems) / 1e6, 4 * max(all_elems) / 1e6,
                                      len(elems), 4 * float(np.mean(elems)) / 1e6)}
-        # MFMA side: the weight-gradient kernel of the data convolutions (its profile slot accounts FLOPs)
-        ms, n = prof.get('conv_wgrad', (0.0, 0))
-        mfma = None
-        if n:
-            flops = prof_bytes.get('conv_wgrad', 0.0)
-            rms, rn = prof.get('conv_wgrad_reduce', (0.0, 0))
-            tf = flops / (ms * 1e-3) / 1e12
-            mfma = {'bound': 'mfma', 'kernel': 'k_conv3x3_wgrad (weight gradient of the 3x3 data convolutions, stride 1 / 2, on '
-                    'v_mfma_f32_32x32x2_f32; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)',
-                    'achieved': round(tf, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                    # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,
-                    # profiles/pmc_traffic.json): the inputs once or twice (row-band halos) + the 37.7 MB of split-K
-                    # partial tiles; an order of magnitude below what 80 us of HBM time could move -- MFMA-bound
-                    'traffic': pmc_traffic('k_conv3x3_wgrad', 'in_situ_per_launch') if args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32 else None,
-                    'traffic_source': 'profiles/pmc_traffic.json: k_conv3x3_wgrad (average over the 16 launches of a config-R step); matrix-core counters: profiles/r04_pmc_mfma_wgrad_bench.json (SQ_VALU_MFMA_BUSY_CYCLES = 64 x the MFMA count exactly)',
-                    'flops_per_launch': int(flops / n), 'avg_us': round(1000.0 * ms / n, 2),
-                    'launches_per_step': round(n / sampled, 1), 'us_per_step': round(1000.0 * ms / sampled, 1),
-                    'reduce_us_per_step': round(1000.0 * rms / sampled, 1),
-                    'achieved_incl_reduce': round(flops / ((ms + rms) * 1e-3) / 1e12, 1),
-                    'note': 'algorithmic FLOPs = 2 * Co * Ci * 9 * N * OH * OW per launch (SURVEY.md 8(d)), summed over '
-                            'the timed launches / their summed kernel time'}
+        # MFMA side: the convolution kernels (their profile slots account ALGORITHMIC FLOPs); the one with the most time
+        # per step is `mfma`, all of them are listed in roofline_mfma_kernels
+        MFMA_SLOTS = {
+            'conv_wgrad_b3': ('k_conv3x3_wgrad_b3 (weight gradient of the 3x3 stride-1 data convolutions on '
+                              'v_mfma_f32_32x32x16_bf16: fp32 operands split exactly into three bf16 words, six of the nine '
+                              'products, fp32 accumulation; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)', 6.0),
+            'conv_wgrad': ('k_conv3x3_wgrad / k_conv1x1s2_wgrad / k_conv_stem_wgrad (the other weight gradients, on '
+                           'v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv_fwd': ('k_conv_gemm (forward of the data convolutions it owns, on v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv_dgrad': ('k_conv_gemm / k_conv_dgrad_s2x4 (backward-data, on v_mfma_f32_32x32x2_f32)', 1.0)}
+        rms, rn = prof.get('conv_wgrad_reduce', (0.0, 0))
+        mfma, mfma_all = None, {}
+        for slot, (what, issued) in MFMA_SLOTS.items():
+            ms, n = prof.get(slot, (0.0, 0))
+            if not n:
+                continue
+            flops = prof_bytes.get(slot, 0.0)
+            tf = flops / (ms * 1e-3) / 1e12                  # algorithmic
+            peak = MFMA_BF16_PEAK_TFLOPS if issued > 1 else MFMA_F32_PEAK_TFLOPS
+            rec = {'bound': 'mfma', 'kernel': what, 'achieved': round(tf * issued, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                   'frac': round(tf * issued / peak, 4), 'traffic': None, 'traffic_source': None,
+                   'algorithmic_TFLOPs': round(tf, 1), 'mfma_flops_per_algorithmic_flop': issued,
+                   'flops_per_launch': int(flops / n), 'avg_us': round(1000.0 * ms / n, 2),
+                   'launches_per_step': round(n / sampled, 1), 'us_per_step': round(1000.0 * ms / sampled, 1),
+                   'note': 'algorithmic FLOPs = 2 * Co * Ci * taps * N * OH * OW per launch (SURVEY.md 8(d)), summed over the '
+                           'timed launches / their summed kernel time; `achieved` = the FLOPs the matrix cores execute'}
+            if issued > 1:
+                rec['algorithmic_over_fp32_mfma_peak'] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
+                rec['note'] += (' (6 bf16 MFMA products per fp32 product) against the dense bf16 peak; the algorithmic rate is '
+                                'also given against the fp32 MFMA peak (%.1f TFLOP/s), which an fp32-MFMA kernel cannot exceed'
+                                % MFMA_F32_PEAK_TFLOPS)
+            if slot.startswith('conv_wgrad'):
+                rec['reduce_us_per_step_all_wgrads'] = round(1000.0 * rms / sampled, 1)
+            if slot == 'conv_wgrad' and args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32:
+                # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,
+                # profiles/pmc_traffic.json), recorded when this slot still held all 16 3x3 launches
+                rec['traffic'] = pmc_traffic('k_conv3x3_wgrad', 'in_situ_per_launch')
+                rec['traffic_source'] = 'profiles/pmc_traffic.json: k_conv3x3_wgrad (fp32-MFMA instances, round-4 record)'
+            mfma_all[slot] = rec
+        if mfma_all:
+            mfma = max(mfma_all.values(), key=lambda r: r['us_per_step'])
+            out['roofline_mfma_kernels'] = mfma_all
         # `roofline` = the dominant hand-written kernel of the step by time; both sides are always reported
         if mfma is not None and mfma['us_per_step'] >= a['us_per_step']:
             out['roofline'], out['roofline_hbm'] = mfma, hbm

@@ -4082,14 +4082,6 @@ template <class C>
 void launch_wgrad_b3(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
                      hipStream_t st) {
     const int grid = p.splits * p.tiles_co * p.tiles_ci;
-    static const int dbg = getenv("DEEPIPR_B3_DBG") ? atoi(getenv("DEEPIPR_B3_DBG")) : 0;
-#define B3_DBG(D)                                                                                                    \
-    case D:                                                                                                          \
-        DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad_b3<C, D>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H,     \
-                       p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split);                                        \
-        return;
-    switch (dbg) { B3_DBG(1) B3_DBG(6) B3_DBG(16) B3_DBG(17) B3_DBG(22) default: break; }
-#undef B3_DBG
     DEEPIPR_LAUNCH(prof, (k_conv3x3_wgrad_b3<C>), dim3(grid), dim3(kWgThreads), st, x, dy, part, Ci, Co, H, p.tiles_co,
                    p.tiles_ci, p.chunks, p.chunks_per_split);
 }
@@ -4138,7 +4130,7 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
         return check_launch("conv_wgrad");
     }
     {
-        ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
+        ProfScope prof(p.cfg >= 4000 ? DEEPIPR_K_CONV_WGRAD_B3 : DEEPIPR_K_CONV_WGRAD, st);
         prof.bytes = 2.0 * Co * Ci * p.taps * static_cast<double>(N) * (H / stride) * (W / stride);     // FLOPs, not bytes: this kernel's roofline is the MFMA peak
 #define DEEPIPR_WGRAD_1X1(...)                                                                                        \
     DEEPIPR_LAUNCH(prof, (k_conv1x1s2_wgrad<W1Cfg<__VA_ARGS__>>), dim3(grid), dim3(256), st, x, dy, part, Ci, Co, H,   \
@@ -4152,7 +4144,7 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
             case 2116: launch_wgrad<WgCfg<1, 16, 8, 1, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 2108: launch_wgrad<WgCfg<1, 8, 8, 2, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 2104: launch_wgrad<WgCfg<1, 4, 4, 4, 32>>(prof, p, x, dy, part, Ci, Co, H, st); break;
-            case 4032: launch_wgrad_b3<WbCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
+case 4032: launch_wgrad_b3<WbCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 4016: launch_wgrad_b3<WbCfg<16, 4, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 4008: launch_wgrad_b3<WbCfg<8, 8, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;
             case 216: launch_wgrad<WgCfg<2, 16, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st); break;

@@ -658,9 +658,9 @@ class HipKernels:
         return v
 
     def set_conv_arith(self, mode):
-        """'bf16x3' (default: fp32 operands split exactly into three bf16 words, six products on the bf16 matrix cores,
-        fp32 accumulation -- one fp32 rounding per product) or 'fp32' (the fp32 MFMA) for the 3x3 stride-1 weight
-        gradients; process-wide (deepipr_conv_set_arith).  -> the previous mode."""
+        """'fp32' (default: the fp32 MFMA) or 'bf16x3' (opt-in, also DEEPIPR_CONV_ARITH=bf16x3: fp32 operands split exactly
+        into three bf16 words, six products on the bf16 matrix cores, fp32 accumulation -- one fp32 rounding per product)
+        for the 3x3 stride-1 weight gradients; process-wide (deepipr_conv_set_arith).  -> the previous mode."""
         before = self.conv_arith()
         _lib.check(_lib.lib().deepipr_conv_set_arith({'fp32': 0, 'bf16x3': 1}[mode]), 'conv_set_arith')
         self._wgrad_ws.clear()

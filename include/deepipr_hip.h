@@ -83,7 +83,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_WGRAD_REDUCE 22
 #define DEEPIPR_K_CONV_FWD 23           /* FLOPs, like DEEPIPR_K_CONV_WGRAD */
 #define DEEPIPR_K_CONV_DGRAD 24
-#define DEEPIPR_PROFILE_KERNELS 25
+#define DEEPIPR_K_CONV_WGRAD_B3 25      /* the bf16x3 weight gradient: ALGORITHMIC FLOPs (it issues six times as many on the bf16 MFMA) */
+#define DEEPIPR_PROFILE_KERNELS 26
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -426,13 +427,17 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
  *           igemm_wrw_gtcx35_nhwc + batched_transpose_* + SubTensorOpWithScalar1d (profiles/r03_steady_state.md).
  * x [N][Ci][H][W]   dy [N][Co][H][W]   dW [Co][Ci][3][3]   m [2][Ci*9] double   all pointers 16-byte aligned
  *
- * Arithmetic (ABI v8).  The 3x3 stride-1 instances on maps 8 / 16 / 32 wide run, by default, on the bf16 matrix cores
- * with every fp32 operand split EXACTLY into three bf16 words (x = h + m + l) and six of the nine cross products
- * accumulated in fp32 ("bf16x3": v_mfma_f32_32x32x16_bf16 multiplies at 16x the rate of the fp32 MFMA; the three products
- * left out are below 2^-24 |x y|, so a product carries the error of ONE fp32 rounding; still a fixed summation order,
- * still bit-reproducible; one-hot inputs still give exact results).  deepipr_conv_set_arith(0) -- or DEEPIPR_CONV_ARITH=fp32
- * in the environment at load time -- restores the fp32 MFMA for those shapes; deepipr_conv_get_arith reports the mode.
- * The setting is process-wide and read when a call is planned: do not change it between a workspace query and its call. */
+ * Arithmetic (ABI v8).  Default: fp32 in, fp32 MFMA, fp32 out, as described above.  Opt-in -- deepipr_conv_set_arith(1),
+ * or DEEPIPR_CONV_ARITH=bf16x3 in the environment at load time -- the 3x3 stride-1 instances on maps 8 / 16 / 32 wide run
+ * on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 words (x = h + m + l) and six of the nine
+ * cross products accumulated in fp32 ("bf16x3": v_mfma_f32_32x32x16_bf16 multiplies at 16x the rate of the fp32 MFMA; the
+ * three products left out are below 2^-24 |x y|, so a product carries the error of ONE fp32 rounding; still a fixed
+ * summation order, still bit-reproducible; one-hot inputs still give exact results; operands below about 2^-110 lose the
+ * third word to bf16's subnormal range and are then carried with 16 significant bits).  Measured against a float64
+ * convolution the result is as accurate as the fp32-MFMA kernel's and closer than the vendor library's fp32 solvers
+ * (tests/test_conv_wgrad_gpu.py, profiles/r04_wgrad_bench_bf16x3.json); it is opt-in because it is not the fp32
+ * multiply the reference's `self.conv(x)` names.  deepipr_conv_get_arith reports the mode.  The setting is process-wide
+ * and read when a call is planned: do not change it between a workspace query and its call. */
 int deepipr_conv_set_arith(int mode);          /* 0: fp32 MFMA, 1: bf16x3 */
 int deepipr_conv_get_arith(void);
 size_t deepipr_conv_wgrad_workspace_bytes(int N, int Ci, int Co, int H, int W, int kh, int kw, int stride, int pad);

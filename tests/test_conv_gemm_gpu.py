@@ -117,7 +117,8 @@ def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
         _lib.profile_enable(False)
         prof = _lib.profile_read()
         res[mode] = (y.detach(), x.grad, [p.grad for p in blk.parameters()],
-                     tuple(int(prof[k][1]) for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad')))
+                     (int(prof['conv_fwd'][1]), int(prof['conv_dgrad'][1]),
+                      int(prof['conv_wgrad'][1]) + int(prof['conv_wgrad_b3'][1])))     # fp32-MFMA + bf16x3 instances
     assert res['all'][3] == (3, 3, 3) and res['auto'][3] == (2, 2, 3) and res['0'][3] == (0, 0, 0)
     for mode in ('all', 'auto'):
         for a, b in zip([res[mode][0], res[mode][1]] + res[mode][2], [res['0'][0], res['0'][1]] + res['0'][2]):

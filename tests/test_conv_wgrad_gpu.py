@@ -1,9 +1,12 @@
-"""deepipr_conv_wgrad -- the data convolution's weight gradient on the fp32 matrix cores -- against the oracle.
+"""deepipr_conv_wgrad -- the data convolution's weight gradient on the matrix cores -- against the oracle.
 
 The reference op is the weight half of the autograd backward of `self.conv(x)` (models/layers/passportconv2d.py:218,
 models/layers/conv2d.py:31), i.e. ATen's convolution_backward; the oracle here is that same ATen op evaluated in
 float64 (oracle/torch_ref.py composes its layers from it).  Bar: 1e-5 of the gradient's scale (fp32 accumulation over up
-to 131 072 products; measured 3-6e-7, the vendor library's own fp32 result sits at 4e-7 - 1e-6), bit-reproducible."""
+to 131 072 products; measured 3-6e-7, the vendor library's own fp32 result sits at 4e-7 - 1e-6), bit-reproducible.
+Every test runs in both arithmetic modes of the 3x3 stride-1 instances: 'fp32' (the default: the fp32 MFMA) and 'bf16x3'
+(opt-in: fp32 operands split exactly into three bf16 words, six products on the bf16 matrix cores, fp32 accumulation);
+the shapes the bf16x3 kernel does not cover take the fp32 MFMA either way."""
 import numpy as np
 import pytest
 import torch
@@ -12,11 +15,13 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.fixture(scope='module')
-def K():
+@pytest.fixture(scope='module', params=['fp32', 'bf16x3'])
+def K(request):
     from deepipr_amd.passport_ops import kernels
     assert torch.cuda.is_available(), 'needs an MI355X'
-    return kernels
+    before = kernels.set_conv_arith(request.param)
+    yield kernels
+    kernels.set_conv_arith(before)
 
 
 def _ref(x, dy, wshape, stride=1, pad=1):
@@ -82,6 +87,50 @@ def test_wgrad_sees_the_zero_padding_and_every_tap(K, st):
     ref = _ref(x, dy, (c, c, 3, 3), st)
     assert float(ref.abs().sum()) > 0
     assert torch.equal(got.double(), ref)                               # small integers: exact in fp32
+
+
+@pytest.mark.parametrize('shape', [(128, 64, 64, 32, 32), (128, 128, 128, 16, 16), (128, 256, 256, 8, 8), (32, 64, 128, 16, 16)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_bf16x3_is_as_accurate_as_the_fp32_mfma_and_the_library(K, shape):
+    """The claim behind the opt-in arithmetic (include/deepipr_hip.h, "Arithmetic"): against the float64 oracle the
+    bf16x3 result carries the error of an fp32 computation -- RMS error within 2x of the fp32-MFMA kernel's (it is a
+    different summation order: the K-groups combine differently) and not above 1.5x the vendor library's fp32 result,
+    worst element within 1e-6 of scale; operands spread over 22 binary orders of magnitude make no difference (a bf16 word
+    has fp32's exponent range)."""
+    if K.conv_arith() != 'bf16x3':
+        pytest.skip('compares the two modes itself')
+    n, ci, co, h, w = shape
+    wshape = (co, ci, 3, 3)
+    for xs, ds in ((1.0, 1.0), (1e-12, 1e10)):
+        x, dy = _rand((n, ci, h, w), 11) * xs, _rand((n, co, h, w), 12) * ds
+        ref = _ref(x, dy, wshape)
+        scale = float(ref.abs().max())
+        rms = lambda a: float(((a.double() - ref) ** 2).mean().sqrt()) / scale
+        b3 = K.conv_wgrad(x, dy, wshape, 1, 1)
+        K.set_conv_arith('fp32')
+        try:
+            f32 = K.conv_wgrad(x, dy, wshape, 1, 1)
+        finally:
+            K.set_conv_arith('bf16x3')
+        lib = torch.ops.aten.convolution_backward(dy, x, torch.empty(wshape, device=DEV), None, [1, 1], [1, 1], [1, 1], False,
+                                                  [0, 0], 1, [False, True, False])[1]
+        assert not torch.equal(b3, f32)                                     # really two different kernels
+        assert rms(b3) <= 2.0 * rms(f32) and rms(b3) <= 1.5 * rms(lib), (rms(b3), rms(f32), rms(lib))
+        assert float((b3.double() - ref).abs().max()) <= 1e-6 * scale
+
+
+def test_bf16x3_split_is_exact_for_every_fp32_value(K):
+    """x = h + m + l: with a one-hot dy every dW entry is ONE fp32 value of x passed through the three-way split and the
+    fp32 accumulator -- any 24-bit significand, any sign, magnitudes from 1e-25 to 1e25, must come back bit for bit
+    (below about 2^-110 the third word of the split leaves bf16's normal range: include/deepipr_hip.h)."""
+    n, c, h = 1, 64, 8
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = (torch.randn(n, c, h, h, generator=g) * torch.pow(10.0, torch.randint(-25, 26, (n, c, h, h), generator=g).float())).to(DEV)
+    dy = torch.zeros(n, c, h, h, device=DEV)
+    dy[0, :, 3, 4] = 1.0                                                 # dW[co][ci][r][s] = x[0][ci][3 + r - 1][4 + s - 1]
+    got = K.conv_wgrad(x, dy, (c, c, 3, 3), 1, 1)
+    want = x[0, :, 2:5, 3:6].unsqueeze(0).expand(c, c, 3, 3)
+    assert torch.equal(got, want)
 
 
 def test_rank2_term_fused_into_the_1x1_reduction_equals_the_separate_update(K):
