@@ -896,7 +896,11 @@ OWN_S1_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_S1_MIN_POSITIONS', 3
 
 
 def _own_policy(n, h, w, k, stride):
-    if OWN_CONV == 'all':
+    # torch.backends.cudnn.deterministic / torch.use_deterministic_algorithms: this library's kernels are bit-reproducible,
+    # the vendor library's are not always (MIOpen's immediate mode can pick a split-K backward-data solver that accumulates
+    # with atomics: profiles/r03_determinism.md) -- so a run that asks for determinism takes the own kernel wherever one
+    # exists, whatever the speed policy says
+    if OWN_CONV == 'all' or torch.backends.cudnn.deterministic or torch.are_deterministic_algorithms_enabled():
         return True
     if stride == 1:
         return k == 3 and OWN_S1_MIN_POSITIONS > 0 and n * h * w >= OWN_S1_MIN_POSITIONS

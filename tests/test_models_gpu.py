@@ -391,6 +391,7 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
                 # counted by wrapping .forward: a HOOK on a submodule makes DualBranch take the two full passes
                 stem, stem_inner = net.convbnrelu_1.conv, net.convbnrelu_1.conv.forward
                 stem.forward = lambda inp, _f=stem_inner: (calls.__setitem__('n', calls['n'] + 1), _f(inp))[1]
+            if graph:
                 step = GraphedTrainStep(train_step_v23, dual, opt, x, y)
                 outs = [tuple(float(v) for v in step(x, y)) for _ in range(3)]
             else:
