@@ -401,6 +401,13 @@ def main():
         again = D.gradient_digest(probe.pop('grads'), device)
         rb, rc, rd = D.digests_agree(first, again)
         repeat = {'bitwise': rb, 'weights_1e-5': rc, **rd}
+        # ... and the verdict that does not depend on the vendor library being deterministic: the ranks differ from one
+        # another by no more than (4 x) what the worst rank differs from itself on a repeat, or by less than 1e-5
+        worst = torch.tensor([rd['worst_rel_weights']], dtype=torch.float64, device='cpu' if tdist.get_backend() == 'gloo' else device)
+        tdist.all_reduce(worst, op=tdist.ReduceOp.MAX)
+        repeat['worst_rel_weights_any_rank'] = float(worst.item())
+        repeat['ranks_differ_like_a_repeat'] = bool(agree_tol or (agree_detail or {}).get('worst_rel_weights', 0.0)
+                                                    <= 4.0 * float(worst.item()))
     probe.clear()
     if keep0 is not None:                                  # every rank back on the broadcast state (norm statistics moved)
         with torch.no_grad():
