@@ -94,6 +94,9 @@ SIGNATURES = {
     'deepipr_conv_supported': (_int, [_int] * 9),
     'deepipr_conv_fwd': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp]),
     'deepipr_conv_dgrad': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp]),
+    'deepipr_conv_workspace_bytes': (_sz, [_int] * 9),
+    'deepipr_conv_fwd_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
+    'deepipr_conv_dgrad_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
     'deepipr_conv_set_arith': (_int, [_int]),
     'deepipr_conv_get_arith': (_int, []),
     'deepipr_conv_wgrad_workspace_bytes': (_sz, [_int] * 9),
@@ -168,7 +171,7 @@ def check(rc, what):
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
-                   'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3']
+                   'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum']
 
 
 class ExternalEvent:

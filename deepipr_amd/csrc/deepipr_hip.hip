@@ -4190,36 +4190,51 @@ case 4032: launch_wgrad_b3<WbCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st)
 namespace {
 template <class C, bool DGRAD>
 void launch_gemm(ProfScope &prof, const FwPlan &p, const float *wgt, const float *in, float *out, int Cin, int M, int H,
-                 hipStream_t st) {
-    DEEPIPR_LAUNCH(prof, (k_conv_gemm<C, DGRAD>), dim3(p.grid), dim3(256), st, wgt, in, out, Cin, M, H, p.bands);
+                 hipStream_t st, float *ws) {
+    if (ws) DEEPIPR_LAUNCH(prof, (k_conv_gemm<C, DGRAD>), dim3(p.grid * p.splits), dim3(256), st, wgt, in, out, Cin, M, H, p.bands,
+                           ws, p.grid, p.cps, p.slab);
+    else DEEPIPR_LAUNCH(prof, (k_conv_gemm<C, DGRAD>), dim3(p.grid), dim3(256), st, wgt, in, out, Cin, M, H, p.bands,
+                        static_cast<float *>(nullptr), p.grid, Cin, p.slab);
 }
 
 template <bool DGRAD>
 int conv_gemm(int slot, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, int W, int k, int stride,
-              int pad, hipStream_t st, const char *what) {
+              int pad, hipStream_t st, const char *what, void *workspace, size_t workspace_bytes) {
     const FwPlan p = plan_conv_gemm(N, Cin, M, H, W, k, stride, pad);
     if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "%s: shape outside the kernel (use the library's convolution)", what);
-    if (!aligned16(wgt) || !aligned16(in) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
+    if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))
+        return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
+    // split K needs its slabs: without a workspace (the entry points of ABI v7) the plain form runs
+    float *ws = (p.splits > 1 && workspace && workspace_bytes >= p.splits * p.slab * sizeof(float)) ? static_cast<float *>(workspace) : nullptr;
+    {
     ProfScope prof(slot, st);
     prof.bytes = 2.0 * M * Cin * k * k * static_cast<double>(N) * (H / stride) * (W / stride);       // FLOPs
     switch (p.cfg) {
-        case 11: launch_gemm<FwCfg<1, 9, 32, 8, 1, 4, 1, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
-        case 21: launch_gemm<FwCfg<1, 9, 32, 2, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
-        case 31: launch_gemm<FwCfg<1, 9, 16, 8, 1, 2, 2, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
-        case 41: launch_gemm<FwCfg<1, 9, 16, 4, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
-        case 51: launch_gemm<FwCfg<1, 9, 8, 8, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
-        case 61: launch_gemm<FwCfg<1, 9, 4, 4, 4, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st); break;
+        case 11: launch_gemm<FwCfg<1, 9, 32, 8, 1, 4, 1, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+        case 21: launch_gemm<FwCfg<1, 9, 32, 2, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+        case 31: launch_gemm<FwCfg<1, 9, 16, 8, 1, 2, 2, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+        case 41: launch_gemm<FwCfg<1, 9, 16, 4, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+        case 51: launch_gemm<FwCfg<1, 9, 8, 8, 1, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+        case 61: launch_gemm<FwCfg<1, 9, 4, 4, 4, 1, 4, 8>, DGRAD>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
         default:
             if (DGRAD) return fail(DEEPIPR_EUNSUPPORTED, "%s: backward-data of a stride-2 convolution is not a gather", what);
             switch (p.cfg) {
-                case 42: launch_gemm<FwCfg<2, 9, 16, 4, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
-                case 52: launch_gemm<FwCfg<2, 9, 8, 8, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
-                case 62: launch_gemm<FwCfg<2, 9, 4, 4, 4, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
-                case 142: launch_gemm<FwCfg<2, 1, 16, 4, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
-                case 152: launch_gemm<FwCfg<2, 1, 8, 8, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
-                case 162: launch_gemm<FwCfg<2, 1, 4, 4, 4, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st); break;
+                case 42: launch_gemm<FwCfg<2, 9, 16, 4, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+                case 52: launch_gemm<FwCfg<2, 9, 8, 8, 1, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+                case 62: launch_gemm<FwCfg<2, 9, 4, 4, 4, 1, 4, 8>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+                case 142: launch_gemm<FwCfg<2, 1, 16, 4, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+                case 152: launch_gemm<FwCfg<2, 1, 8, 8, 1, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
+                case 162: launch_gemm<FwCfg<2, 1, 4, 4, 4, 1, 4, 16>, false>(prof, p, wgt, in, out, Cin, M, H, st, ws); break;
                 default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
             }
+    }
+    }
+    if (ws) {
+        ProfScope prof(DEEPIPR_K_CONV_SPLIT_SUM, st);
+        prof.bytes = 4.0 * (p.splits + 1.0) * p.slab;
+        const size_t n4 = p.slab / 4;
+        DEEPIPR_LAUNCH(prof, k_conv_sum_slabs, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), st,
+                       reinterpret_cast<const f32x4 *>(ws), reinterpret_cast<f32x4 *>(out), n4, p.splits);
     }
     return check_launch(what);
 }
@@ -4267,20 +4282,36 @@ int deepipr_conv_supported(int N, int Ci, int Co, int H, int W, int k, int strid
     return 0;
 }
 
-int deepipr_conv_fwd(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
-                     void *stream) {
-    if (!x || !w || !y) return fail(DEEPIPR_EINVAL, "conv_fwd: null pointer");
-    return conv_gemm<false>(DEEPIPR_K_CONV_FWD, w, x, y, N, Ci, Co, H, W, k, stride, pad, static_cast<hipStream_t>(stream),
-                            "conv_fwd");
+size_t deepipr_conv_workspace_bytes(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction) {
+    if (direction != 0 && !(direction == 1 && stride == 1)) return 0;
+    const FwPlan p = direction == 0 ? plan_conv_gemm(N, Ci, Co, H, W, k, stride, pad) : plan_conv_gemm(N, Co, Ci, H, W, k, stride, pad);
+    return (p.cfg && p.splits > 1) ? p.splits * p.slab * sizeof(float) : 0;
 }
 
-int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
-                       int pad, void *stream) {
+int deepipr_conv_fwd_ws(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
+                        void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !w || !y) return fail(DEEPIPR_EINVAL, "conv_fwd: null pointer");
+    return conv_gemm<false>(DEEPIPR_K_CONV_FWD, w, x, y, N, Ci, Co, H, W, k, stride, pad, static_cast<hipStream_t>(stream),
+                            "conv_fwd", workspace, workspace_bytes);
+}
+
+int deepipr_conv_fwd(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
+                     void *stream) {
+    return deepipr_conv_fwd_ws(x, w, y, N, Ci, Co, H, W, k, stride, pad, nullptr, 0, stream);
+}
+
+int deepipr_conv_dgrad_ws(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
+                          int pad, void *workspace, size_t workspace_bytes, void *stream) {
     if (!dy || !w || !dx) return fail(DEEPIPR_EINVAL, "conv_dgrad: null pointer");
     if (stride == 2) return conv_dgrad_s2(dy, w, dx, N, Ci, Co, H, W, k, pad, static_cast<hipStream_t>(stream));
     if (stride != 1) return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad: stride 1 or 2 (use the library's backward-data)");
     return conv_gemm<true>(DEEPIPR_K_CONV_DGRAD, w, dy, dx, N, Co, Ci, H, W, k, stride, pad, static_cast<hipStream_t>(stream),
-                           "conv_dgrad");
+                           "conv_dgrad", workspace, workspace_bytes);
+}
+
+int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
+                       int pad, void *stream) {
+    return deepipr_conv_dgrad_ws(dy, w, dx, N, Ci, Co, H, W, k, stride, pad, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -708,10 +708,23 @@ class HipKernels:
             return None
         dev = _chk(x, weight)
         y = torch.empty((n, co, h // stride, w // stride), dtype=torch.float32, device=dev)
+        st = _stream(dev)
+        nbytes = self.conv_workspace(n, ci, co, h, w, k, stride, pad, 0)       # split K over workgroups: deep layers
+        ws = self._scratch(dev, ('conv', st), nbytes) if nbytes else None
         with _on(dev):
-            _lib.check(_lib.lib().deepipr_conv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), n, ci, co, h, w, k, stride,
-                                                  pad, _stream(dev)), 'conv_fwd')
+            _lib.check(_lib.lib().deepipr_conv_fwd_ws(x.data_ptr(), weight.data_ptr(), y.data_ptr(), n, ci, co, h, w, k, stride,
+                                                     pad, ws, nbytes, st), 'conv_fwd')
         return y
+
+    _conv_ws = {}
+
+    def conv_workspace(self, n, ci, co, h, w, k, stride, pad, direction):
+        """Bytes of split-K workspace deepipr_conv_fwd_ws / _dgrad_ws use for this problem (0: the plain form)."""
+        key = (n, ci, co, h, w, k, stride, pad, direction)
+        v = self._conv_ws.get(key)
+        if v is None:
+            v = self._conv_ws[key] = int(_lib.lib().deepipr_conv_workspace_bytes(*key))
+        return v
 
     def conv_dgrad(self, dy, weight, x_shape, stride, pad):
         """Gradient of conv2d(x, weight) with respect to x, or None when the shape is outside the kernel."""
@@ -721,9 +734,12 @@ class HipKernels:
             return None
         dev = _chk(dy, weight)
         dx = torch.empty((n, ci, h, w), dtype=torch.float32, device=dev)
+        st = _stream(dev)
+        nbytes = self.conv_workspace(n, ci, co, h, w, k, stride, pad, 1)
+        ws = self._scratch(dev, ('conv', st), nbytes) if nbytes else None
         with _on(dev):
-            _lib.check(_lib.lib().deepipr_conv_dgrad(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, ci, co, h, w, k,
-                                                    stride, pad, _stream(dev)), 'conv_dgrad')
+            _lib.check(_lib.lib().deepipr_conv_dgrad_ws(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, ci, co, h, w, k,
+                                                       stride, pad, ws, nbytes, st), 'conv_dgrad')
         return dx
 
     def sgd_chunk(self):
@@ -913,19 +929,32 @@ def _own_policy(n, h, w, k, stride, backward_data=False):
     return k == 1 or n * (h // 2) * (w // 2) >= OWN_MIN_POSITIONS
 
 
+def _own_split(n, ci, co, h, wd, k, stride, pad, direction):
+    """The planner splits K at least four ways for this call (few output positions: the deep layers at small batches, where
+    the 64 x 64 tiles alone fill a quarter of the chip or less) -- there the own kernel beats the vendor library with its
+    layout shims (512 -> 512 on 4x4 maps at batch 32: 34 us against 29 + 15; tools/conv_bench.py --batch 32,
+    profiles/r04_conv_bench_bs32.json)."""
+    nbytes = kernels.conv_workspace(n, ci, co, h, wd, k, stride, pad, direction)
+    return nbytes >= 4 * 4 * n * (co if direction == 0 else ci) * (h // stride if direction == 0 else h) * (wd // stride if direction == 0 else wd)
+
+
 def _own_fwd(x_in, w, stride, pad):
     if OWN_CONV == '0' or not _own_ok(x_in, w):
         return False
     n, ci, h, wd = x_in.shape
-    return _own_policy(n, h, wd, w.shape[2], stride) and kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
+    if not kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0):
+        return False
+    return _own_policy(n, h, wd, w.shape[2], stride) or _own_split(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
 
 
 def _own_dgrad(x_shape, w, stride, pad, dy):
     if OWN_CONV == '0' or not _own_ok(dy, w):
         return False
     n, ci, h, wd = x_shape
+    if not kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1):
+        return False
     return (_own_policy(n, h, wd, w.shape[2], stride, backward_data=True)
-            and kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1))
+            or _own_split(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1))
 
 
 def _own_wgrad(x_in, w, stride, pad):

@@ -84,7 +84,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_FWD 23           /* FLOPs, like DEEPIPR_K_CONV_WGRAD */
 #define DEEPIPR_K_CONV_DGRAD 24
 #define DEEPIPR_K_CONV_WGRAD_B3 25      /* the bf16x3 weight gradient: ALGORITHMIC FLOPs (it issues six times as many on the bf16 MFMA) */
-#define DEEPIPR_PROFILE_KERNELS 26
+#define DEEPIPR_K_CONV_SPLIT_SUM 26     /* sum of the split-K output slabs of deepipr_conv_fwd_ws / _dgrad_ws (bytes) */
+#define DEEPIPR_PROFILE_KERNELS 27
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -467,6 +468,17 @@ int deepipr_conv_fwd(const float *x, const float *w, float *y, int N, int Ci, in
                      void *stream);
 int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
                        int pad, void *stream);
+/* The same two with a workspace (ABI v8).  Where the 64 x 64 output tiles alone would leave the chip short of two
+ * workgroups per CU -- the 4x4 / 8x8 maps of the deep layers, small batches -- K = Cin * 9 is split over workgroups: each
+ * writes a partial output into its slab of the workspace, a second launch adds the slabs in split order (fixed order, no
+ * atomics: bit-reproducible like the plain form).  deepipr_conv_workspace_bytes returns what the call needs (0: the
+ * plain form runs; stride-2 backward-data never splits); with no or too small a workspace the plain form runs.
+ * 16-byte aligned workspace. */
+size_t deepipr_conv_workspace_bytes(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction);
+int deepipr_conv_fwd_ws(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int deepipr_conv_dgrad_ws(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
+                          int pad, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

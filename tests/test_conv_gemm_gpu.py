@@ -36,7 +36,8 @@ def _dgrad64(dy, x, w, st, pad):
 SHAPES = [
     (128, 64, 64, 32, 32, 3, 1), (8, 64, 128, 32, 32, 3, 1), (128, 128, 128, 16, 16, 3, 1), (4, 128, 64, 16, 16, 3, 1),
     (128, 256, 256, 8, 8, 3, 1), (3, 256, 128, 8, 8, 3, 1), (128, 512, 512, 4, 4, 3, 1), (4, 192, 64, 4, 4, 3, 1),
-    (32, 64, 64, 32, 32, 3, 1), (32, 512, 512, 4, 4, 3, 1),
+    (32, 64, 64, 32, 32, 3, 1), (32, 512, 512, 4, 4, 3, 1), (32, 256, 256, 8, 8, 3, 1), (8, 512, 512, 4, 4, 3, 1),
+    (4, 512, 256, 4, 4, 3, 1), (16, 256, 128, 8, 8, 3, 1),
     (128, 64, 128, 32, 32, 3, 2), (3, 64, 64, 32, 32, 3, 2), (128, 128, 256, 16, 16, 3, 2), (5, 128, 64, 16, 16, 3, 2),
     (128, 256, 512, 8, 8, 3, 2), (4, 256, 64, 8, 8, 3, 2), (32, 256, 512, 8, 8, 3, 2),
     (128, 64, 128, 32, 32, 1, 2), (2, 64, 64, 32, 32, 1, 2), (128, 128, 256, 16, 16, 1, 2), (128, 256, 512, 8, 8, 1, 2),
@@ -60,6 +61,43 @@ def test_forward_and_backward_data_match_the_float64_oracle(K, shape):
     ref = _dgrad64(dy, x, wt, st, pad)
     assert float((dx.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     assert torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, st, pad))
+
+
+@pytest.mark.parametrize('shape', [(32, 512, 512, 4, 4, 3, 1), (128, 512, 512, 4, 4, 3, 1), (32, 256, 256, 8, 8, 3, 1),
+                                   (32, 256, 512, 8, 8, 3, 2), (8, 320, 192, 4, 4, 3, 1)], ids=lambda s: 'x'.join(map(str, s)))
+def test_split_k_form_agrees_with_the_plain_form(K, shape):
+    """Few output positions (deep layers, small batches): K = Cin * 9 is split over workgroups, partial outputs summed by
+    a second launch in split order (deepipr_conv_fwd_ws / _dgrad_ws).  Same result as the plain form -- the ABI v7 entry
+    points without a workspace -- to rounding (a different association of the same sum), both against float64, both
+    bit-reproducible; the planner really splits these shapes."""
+    from deepipr_amd import _lib
+    n, ci, co, h, w, k, st = shape
+    pad = k // 2
+    x, wt = _rand((n, ci, h, w), 21 + n), _rand((co, ci, k, k), 22 + co, 0.05)
+    dy = _rand((n, co, h // st, w // st), 23 + ci)
+    assert K.conv_workspace(n, ci, co, h, w, k, st, pad, 0) > 0
+    y = K.conv_fwd(x, wt, st, pad)
+    plain = torch.empty_like(y)
+    _lib.check(_lib.lib().deepipr_conv_fwd(x.data_ptr(), wt.data_ptr(), plain.data_ptr(), n, ci, co, h, w, k, st, pad, None),
+               'conv_fwd')
+    ref = _conv64(x, wt, st, pad)
+    scale = float(ref.abs().max())
+    assert not torch.equal(y, plain)
+    assert float((y - plain).abs().max()) <= 2e-6 * scale
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * scale and float((plain.double() - ref).abs().max()) <= 1e-5 * scale
+    assert torch.equal(y, K.conv_fwd(x, wt, st, pad))
+    if st == 1:                                             # stride-2 backward-data never splits
+        assert K.conv_workspace(n, ci, co, h, w, k, st, pad, 1) > 0
+        dx = K.conv_dgrad(dy, wt, x.shape, st, pad)
+        plain = torch.empty_like(dx)
+        _lib.check(_lib.lib().deepipr_conv_dgrad(dy.data_ptr(), wt.data_ptr(), plain.data_ptr(), n, ci, co, h, w, k, st, pad,
+                                                 None), 'conv_dgrad')
+        ref = _dgrad64(dy, x, wt, st, pad)
+        scale = float(ref.abs().max())
+        assert float((dx - plain).abs().max()) <= 2e-6 * scale and float((dx.double() - ref).abs().max()) <= 1e-5 * scale
+        assert torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, st, pad))
+    else:
+        assert K.conv_workspace(n, ci, co, h, w, k, st, pad, 1) == 0
 
 
 @pytest.mark.parametrize('k,st', [(3, 1), (3, 2), (1, 2)])
