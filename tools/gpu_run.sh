@@ -7,6 +7,8 @@
 #   tools/gpu_run.sh profiles <round tag>            the round's measurement set (steady states, ImageNet-shape lines)
 #   tools/gpu_run.sh bench <tag>                     bench lines R / V3 / P shard with their roofline objects
 #   tools/gpu_run.sh conv                            conv kernels (wgrad / fwd / dgrad) against the vendor library, per shape
+#   tools/gpu_run.sh nrank                           the N > 1 code path of bench.py rehearsed on one GPU -> gpurun_out/<round>_nrank_rehearsal.jsonl
+#   tools/gpu_run.sh micro                           tools/micro/mfma_rate.hip: issue interval of the bf16 MFMA alone and beside vector instructions
 # Run through gpurun from the repo root:  gpurun --timeout 1800 -- 'tools/gpu_run.sh suite r04_final'
 cmd=$1; shift
 case "$cmd" in
@@ -17,5 +19,7 @@ case "$cmd" in
   profiles) exec tools/gpu_round_profiles.sh "$@" ;;
   bench)    exec tools/gpu_bench_check.sh "$@" ;;
   conv)     python tools/wgrad_bench.py --json gpurun_out/wgrad_bench.json | grep "^{"; exec python tools/conv_bench.py --json gpurun_out/conv_bench.json ;;
-  *)        sed -n 2,11p "$0"; exit 2 ;;
+  nrank)    exec tools/gpu_nrank_rehearsal.sh "$@" ;;
+  micro)    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/mfma_rate.out tools/micro/mfma_rate.hip && exec /tmp/mfma_rate.out ;;
+  *)        sed -n 2,13p "$0"; exit 2 ;;
 esac
