@@ -4,6 +4,8 @@ Checker = oracle/ (numpy + plain PyTorch on the host) and tests/golden/*.npz (ou
 reference).  Tolerances: fp32 results within 1e-4 (north-star bar; most ops are much tighter and say
 so), signature bits and ReLU masks exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1043,18 +1045,14 @@ def test_add_relu_fused_tail(K, shape):
         assert torch.equal(a5.grad, a2.grad)
 
 
-@pytest.mark.miopen_pinned
-def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
-    """Data-parallel form of the graphed step: forward+backward replayed from a hipGraph, FlatSGD's bucketed
-    exchange (forced on in a one-rank nccl group) and the fused SGD kernel run eagerly after each replay.  Must
-    equal the plain eager trajectory."""
+def _graph_replay_exchange_worker(port):
+    """Body of test_graph_replay_with_eager_gradient_exchange; runs in a process of its own (see there)."""
     import torch.distributed as dist
     from deepipr_amd.experiments.graph_step import GraphedTrainStep
     from deepipr_amd.experiments.trainer import train_step_v1
     from deepipr_amd.flat_sgd import FlatSGD
     from deepipr_amd import passport_ops
-    monkeypatch.setenv('DEEPIPR_FORCE_DDP', '1')
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29547', rank=0, world_size=1)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
     bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
     torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
     try:
@@ -1096,7 +1094,33 @@ def test_graph_replay_with_eager_gradient_exchange(monkeypatch):
         passport_ops.kernels.check_exchange()
     finally:
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
-        dist.destroy_process_group()
+
+
+@pytest.mark.miopen_pinned
+def test_graph_replay_with_eager_gradient_exchange(tmp_path):
+    """Data-parallel form of the graphed step: forward+backward replayed from a hipGraph, FlatSGD's bucketed
+    exchange (forced on in a one-rank nccl group) and the fused SGD kernel run eagerly after each replay.  Must
+    equal the plain eager trajectory.
+
+    The body (_graph_replay_exchange_worker) runs in a child process that leaves through os._exit once it has written
+    its verdict: tearing an RCCL communicator down inside the long-lived pytest process aborted the interpreter once in
+    eleven sessions of round 4 (SIGABRT inside destroy_process_group, no message: profiles/r04_pytest_gpu_7_crash.log) --
+    a teardown race of the library, not of the code under test, and it must not be able to take the session with it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out = tmp_path / 'verdict.json'
+    env = dict(os.environ, DEEPIPR_FORCE_DDP='1')           # (the pinned MIOpen environment of conftest.py is inherited)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, '-m', 'tests.test_parity_gpu', str(port), str(out)], cwd=root, env=env,
+                          capture_output=True, text=True, timeout=900)
+    assert out.exists(), 'the worker died before its verdict (rc %s):\n%s\n%s' % (proc.returncode, proc.stdout[-3000:], proc.stderr[-3000:])
+    verdict = json.loads(out.read_text())
+    assert verdict['ok'], verdict['error']
 
 
 def test_product_has_no_cpu_path():
@@ -1162,4 +1186,17 @@ def test_force_passport_paths_on_gpu(golden_dir):
               'private forced', 1e-4, 1e-5)
 
 
-
+if __name__ == '__main__':                                   # the child process of test_graph_replay_with_eager_gradient_exchange
+    import json
+    import sys
+    import traceback
+    verdict = {'ok': True, 'error': None}
+    try:
+        _graph_replay_exchange_worker(int(sys.argv[1]))
+    except BaseException:                                    # noqa: B036 -- the parent re-raises it as an assertion
+        verdict = {'ok': False, 'error': traceback.format_exc()}
+    with open(sys.argv[2], 'w') as f:
+        json.dump(verdict, f)
+        f.flush()
+        os.fsync(f.fileno())
+    os._exit(0)                                              # no communicator teardown, no atexit handlers
