@@ -76,10 +76,11 @@ def build_model(args, device):
 
 
 def _leave():
-    """End of a rank.  With RCCL ranks the process leaves WITHOUT tearing the communicator down: destroy_process_group()
-    aborted the interpreter once in eleven GPU sessions of round 4 (SIGABRT inside the library's teardown, no message;
-    profiles/r04_pytest_gpu_7_crash.log), and a benchmark whose line is already printed must not turn into a non-zero exit
-    code for that.  Everything else (one process, gloo rehearsals, the dry run) shuts down normally."""
+    """End of a rank.  With RCCL ranks the process leaves WITHOUT tearing the communicator down: a benchmark whose line is
+    already printed must not turn into a non-zero exit code because a library thread objects during teardown (the one
+    abort seen there in round 4 was RCCL's watchdog, whose poll had fallen inside a stream capture -- the captures are
+    now preceded by distributed.retire_collectives(); profiles/r04_nccl_flake_probe.txt).  Everything else (one process,
+    gloo rehearsals, the dry run) shuts down normally."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() > 1:
         sys.stdout.flush()

@@ -104,6 +104,21 @@ def barrier():
             dist.barrier()
 
 
+def retire_collectives(seconds=0.5):
+    """Call before a hipGraph capture when an RCCL process group is alive: wait until its watchdog thread has retired every
+    collective issued so far.  The watchdog polls the end event of each unretired collective about every 100 ms; a poll
+    that falls INSIDE a stream capture of the main thread comes back as `hipErrorCapturedEvent` ("operation not permitted
+    on an event last recorded in a capturing stream") on ROCm 7.2 / torch 2.10 -- also in capture_error_mode
+    "thread_local" -- and the watchdog answers by terminating the process.  Measured: one run in five of a process that
+    captures within a few hundred ms of its last collective (tools/nccl_flake_probe.sh,
+    profiles/r04_nccl_flake_probe.txt).  Finished collectives leave the list at the next poll, so: drain the device,
+    then give the watchdog a few polls."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        import time
+        torch.cuda.synchronize()
+        time.sleep(seconds)
+
+
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -101,6 +101,8 @@ class GraphedTrainStep:
             # with a process group alive, RCCL's watchdog thread polls events concurrently: only this thread's calls
             # may be checked against the capture ("thread_local"), otherwise its hipEventQuery aborts the capture
             mode = 'global' if self.optimizer_in_graph else 'thread_local'
+            from deepipr_amd.distributed import retire_collectives
+            retire_collectives()                   # ... and none of its polls may fall inside the capture at all
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
                 self.outputs = self.step_fn(self.model, captured_opt, self.static_data, self.static_target)
         # the gradient tensors the replayed backward writes (graph-pool memory): `.grad` must point at them whenever the

@@ -292,6 +292,8 @@ class StagedStep:
         if self._device_hyper:
             opt.sync_hyper()
         mode = 'thread_local' if torch.distributed.is_available() and torch.distributed.is_initialized() else 'global'
+        from deepipr_amd.distributed import retire_collectives
+        retire_collectives()                       # no RCCL watchdog poll may fall inside the captures below
         pool = torch.cuda.graph_pool_handle()
         self._plan, self._events, self._ranges, state = [], {}, {}, None
         opt.zero_grad(set_to_none=True)
@@ -352,8 +354,14 @@ class StagedStep:
                         # graph next to it (+160 us per step for ResNet18 V1, +560 us for the V2 shard with twice the
                         # dispatches; profiles/r03_ddp_rehearsal*.jsonl).  The host has nothing else to do meanwhile: what
                         # it still has to enqueue for this step and the next takes ~0.3 ms, the graph runs for 2-3 ms more.
+                        # The side stream then waits for NOTHING: a stream that waits for an event whose last record was a
+                        # node of a captured graph is where RCCL's watchdog thread died one run in five ("operation not
+                        # permitted on an event last recorded in a capturing stream" from its hipEventQuery of the
+                        # collective's end event; tools/nccl_flake_probe.sh, profiles/r04_nccl_flake_probe.txt).
                         self._events[k].synchronize()
-                    opt.exchange_stages(lo, hi, after=self._events[k], overlap=True, packed=True)
+                        opt.exchange_stages(lo, hi, after=False, overlap=True, packed=True)
+                    else:
+                        opt.exchange_stages(lo, hi, after=self._events[k], overlap=True, packed=True)
             if tr is not None:
                 t = self._lap(tr, 'buckets', t)
         if self.flat:

@@ -229,7 +229,8 @@ class FlatSGD(torch.optim.Optimizer):
     def exchange_stages(self, lo, hi, after=None, overlap=True, packed=False):
         """Staged mode: pack the gradients of buckets lo..hi-1 into the flat gradient buffer and all-reduce that
         range as ONE message.  overlap=True: on a side stream that first waits for the event `after` (recorded on the
-        main stream behind the stage that finished these gradients), so the main stream can go on with the next
+        main stream behind the stage that finished these gradients; after=False: the caller already held the host
+        until that event had passed, the side stream waits for nothing), so the main stream can go on with the next
         stage; the all-reduce is waited for in step() (or by wait_exchange()).  overlap=False: on the current stream.
         packed=True: the range was packed already (pack_stages, captured in the stage's graph): collective only."""
         if lo >= hi:
@@ -252,7 +253,9 @@ class FlatSGD(torch.optim.Optimizer):
         if cuda and overlap:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.flat_grad.device)
-            if after is not None:
+            if after is False:
+                pass                                # the caller held the HOST until the gradients were there: nothing to wait for
+            elif after is not None:
                 after.wait(self._side)              # a torch.cuda.Event, or the external event of a captured stage
             else:
                 self._side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))

@@ -1047,6 +1047,7 @@ def test_add_relu_fused_tail(K, shape):
 
 def _graph_replay_exchange_worker(port):
     """Body of test_graph_replay_with_eager_gradient_exchange; runs in a process of its own (see there)."""
+    import sys
     import torch.distributed as dist
     from deepipr_amd.experiments.graph_step import GraphedTrainStep
     from deepipr_amd.experiments.trainer import train_step_v1
@@ -1058,6 +1059,7 @@ def _graph_replay_exchange_worker(port):
     try:
         finals = []
         for graphed in (False, True, 'staged', 'staged-exclusive'):
+            print('variant %r: building' % (graphed,), file=sys.stderr, flush=True)
             prod, _ref, x, y = _fullsize_pair(False, 32, 10)
             x, y = x.to(DEV), y.to(DEV)
             opt = FlatSGD(prod.parameters(), **SGD)
@@ -1088,6 +1090,7 @@ def _graph_replay_exchange_worker(port):
                 for i in range(3):
                     train_step_v1(prod, opt, x if i % 2 == 0 else x.flip(0), y if i % 2 == 0 else y.flip(0))
             torch.cuda.synchronize()
+            print('variant %r: three steps done' % (graphed,), file=sys.stderr, flush=True)
             finals.append({k: v.clone() for k, v in prod.state_dict().items()})
         for i, name in ((1, 'one graph + exchange after it'), (2, 'staged, shared'), (3, 'staged, exclusive')):
             states_close(finals[0], finals[i], what='eager vs ' + name)
@@ -1103,9 +1106,12 @@ def test_graph_replay_with_eager_gradient_exchange(tmp_path):
     equal the plain eager trajectory.
 
     The body (_graph_replay_exchange_worker) runs in a child process that leaves through os._exit once it has written
-    its verdict: tearing an RCCL communicator down inside the long-lived pytest process aborted the interpreter once in
-    eleven sessions of round 4 (SIGABRT inside destroy_process_group, no message: profiles/r04_pytest_gpu_7_crash.log) --
-    a teardown race of the library, not of the code under test, and it must not be able to take the session with it."""
+    its verdict.  What this guards against: RCCL's watchdog thread polls the end event of every unretired collective;
+    a poll that falls inside a stream capture comes back as hipErrorCapturedEvent and the watchdog terminates the process
+    (one fresh process in five before distributed.retire_collectives() was put in front of every capture; in the
+    long-lived pytest process it showed once in eleven sessions, as a SIGABRT at destroy_process_group:
+    profiles/r04_pytest_gpu_7_crash.log, r04_nccl_flake_probe.txt).  The product now keeps such polls out of its captures;
+    a library thread that can still abort the interpreter must not be able to take the session with it."""
     import json
     import socket
     import subprocess
