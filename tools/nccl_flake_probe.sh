@@ -13,6 +13,6 @@ run() {
   done
   echo "$* : ok $ok bad $bad"
 }
-run X=1
-run X=2
-run X=3
+run PROBE=1
+run PROBE=2
+run PROBE=3
