@@ -97,6 +97,9 @@ SIGNATURES = {
     'deepipr_conv_workspace_bytes': (_sz, [_int] * 9),
     'deepipr_conv_fwd_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
     'deepipr_conv_dgrad_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
+    'deepipr_conv_set_algo': (_int, [_int]),
+    'deepipr_conv_get_algo': (_int, []),
+    'deepipr_conv_algo_of': (_int, [_int] * 9),
     'deepipr_conv_set_arith': (_int, [_int]),
     'deepipr_conv_get_arith': (_int, []),
     'deepipr_conv_wgrad_workspace_bytes': (_sz, [_int] * 9),
@@ -106,8 +109,9 @@ SIGNATURES = {
 TEST_HOOK_SIGNATURES = {
     'deepipr_debug_tune': (_int, [_c.c_char_p, _int]),
     'deepipr_debug_trace': (_int, [_vp]),
+    'deepipr_debug_wino_trace': (_int, [_vp]),
 }
-ABI_VERSION = 8
+ABI_VERSION = 9
 SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
@@ -171,7 +175,8 @@ def check(rc, what):
 PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'affine_fwd', 'affine_bwd',
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
-                   'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum']
+                   'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum',
+                   'conv_wino_fwd', 'conv_wino_dgrad']
 
 
 class ExternalEvent:

@@ -669,6 +669,29 @@ class HipKernels:
     def conv_arith(self):
         return ('fp32', 'bf16x3')[_lib.lib().deepipr_conv_get_arith()]
 
+    def set_conv_algo(self, algo):
+        """'winograd' (default: F(2x2, 3x3) around the fp32 MFMA for the 3x3 stride-1 forward / backward-data) or 'direct'
+        (the implicit GEMM); process-wide (deepipr_conv_set_algo, also DEEPIPR_CONV_ALGO at load time).  -> the previous one."""
+        before = self.conv_algo()
+        _lib.check(_lib.lib().deepipr_conv_set_algo({'direct': 0, 'winograd': 1}[algo]), 'conv_set_algo')
+        self._conv_ok.clear()
+        self._conv_ws.clear()
+        self._conv_wino.clear()
+        return before
+
+    def conv_algo(self):
+        return ('direct', 'winograd')[_lib.lib().deepipr_conv_get_algo()]
+
+    _conv_wino = {}
+
+    def conv_is_winograd(self, n, ci, co, h, w, k, stride, pad, direction):
+        """This call (deepipr_conv_fwd_ws / _dgrad_ws of this shape) takes the Winograd kernel."""
+        key = (n, ci, co, h, w, k, stride, pad, direction)
+        v = self._conv_wino.get(key)
+        if v is None:
+            v = self._conv_wino[key] = bool(_lib.lib().deepipr_conv_algo_of(*key))
+        return v
+
     def conv_wgrad(self, x, dy, wshape, stride, pad, dgamma=None, dbeta=None, m=None):
         """dW of conv(x, W) for upstream gradient dy, or None when the shape is outside the kernel.  With dgamma /
         dbeta / m the passport branch's rank-2 term is added in the same pass (deepipr_gamma_beta_bwd_acc's result)."""

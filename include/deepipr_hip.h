@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 8
+#define DEEPIPR_ABI_VERSION 9
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -85,7 +85,9 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_DGRAD 24
 #define DEEPIPR_K_CONV_WGRAD_B3 25      /* the bf16x3 weight gradient: ALGORITHMIC FLOPs (it issues six times as many on the bf16 MFMA) */
 #define DEEPIPR_K_CONV_SPLIT_SUM 26     /* sum of the split-K output slabs of deepipr_conv_fwd_ws / _dgrad_ws (bytes) */
-#define DEEPIPR_PROFILE_KERNELS 27
+#define DEEPIPR_K_CONV_WINO_FWD 27      /* Winograd F(2x2, 3x3) forward: EXECUTED FLOPs (the direct sum's / 2.25) */
+#define DEEPIPR_K_CONV_WINO_DGRAD 28
+#define DEEPIPR_PROFILE_KERNELS 29
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -475,6 +477,19 @@ int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
  * plain form runs; stride-2 backward-data never splits); with no or too small a workspace the plain form runs.
  * 16-byte aligned workspace. */
 size_t deepipr_conv_workspace_bytes(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction);
+/* Algorithm of the 3x3 stride-1 pad-1 convolutions, both directions (ABI v9).  1 (default): Winograd F(2x2, 3x3) around the
+ * fp32 MFMA -- the 3x3 filters are transformed (G g G^T) while they are staged, every wavefront transforms its row of the
+ * 4x4 input tiles (B^T d B) straight out of the staged NCHW band, sixteen batched 32 x 32 x 2 MFMA GEMMs over channel pairs,
+ * the output transform in the epilogue: 16 instead of 36 multiplies per 2x2 outputs and channel, NCHW in and out, fixed
+ * summation order (bit-reproducible), exact on small-integer operands; against float64 a few 1e-7 of the output scale (the
+ * algorithm the vendor library runs for these layers on the vector ALUs, miopenSp3AsmConv_*_f2x3).  Any N (ragged image
+ * groups are masked), Ci a multiple of 8, Co of 32, maps 4 / 8 / 16 / 32 wide, H a multiple of 4 / 8 / 8 / 4.
+ * 0: the direct implicit GEMM above (also what every other shape takes).  DEEPIPR_CONV_ALGO=direct|winograd in the
+ * environment at load time sets the default.  Process-wide, read when a call is planned: do not change it between
+ * deepipr_conv_supported / _workspace_bytes and the call.  deepipr_conv_algo_of: the algorithm a call of this shape takes. */
+int deepipr_conv_set_algo(int algo);
+int deepipr_conv_get_algo(void);
+int deepipr_conv_algo_of(int N, int Ci, int Co, int H, int W, int k, int stride, int pad, int direction);
 int deepipr_conv_fwd_ws(const float *x, const float *w, float *y, int N, int Ci, int Co, int H, int W, int k, int stride, int pad,
                         void *workspace, size_t workspace_bytes, void *stream);
 int deepipr_conv_dgrad_ws(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,

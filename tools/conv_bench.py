@@ -39,8 +39,11 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--algo', default=None, choices=['direct', 'winograd'], help='3x3 stride-1 algorithm (default: the library default)')
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
+    if args.algo:
+        K.set_conv_algo(args.algo)
     dev = torch.device('cuda:0')
     out = []
     for ci, co, hw, k, st in SHAPES:
@@ -51,7 +54,8 @@ def main():
         dy = torch.randn(n, co, hw // st, hw // st, generator=g).to(dev)
         conv = lambda a, b: torch.ops.aten.convolution(a, b, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
         y_ref = conv(x.double(), w.double())
-        rec = {'Ci': ci, 'Co': co, 'HW': hw, 'k': k, 'stride': st, 'N': n}
+        rec = {'Ci': ci, 'Co': co, 'HW': hw, 'k': k, 'stride': st, 'N': n,
+               'algo': 'winograd' if K.conv_is_winograd(n, ci, co, hw, hw, k, st, pad, 0) else 'direct'}
         flops = 2.0 * co * ci * k * k * n * (hw // st) ** 2
         y = K.conv_fwd(x, w, st, pad)
         if y is not None:
