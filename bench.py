@@ -697,7 +697,12 @@ def main():
             'conv_wgrad': ('k_conv3x3_wgrad / k_conv1x1s2_wgrad / k_conv_stem_wgrad (the other weight gradients, on '
                            'v_mfma_f32_32x32x2_f32)', 1.0),
             'conv_fwd': ('k_conv_gemm (forward of the data convolutions it owns, on v_mfma_f32_32x32x2_f32)', 1.0),
-            'conv_dgrad': ('k_conv_gemm / k_conv_dgrad_s2x4 (backward-data, on v_mfma_f32_32x32x2_f32)', 1.0)}
+            'conv_dgrad': ('k_conv_gemm / k_conv_dgrad_s2x4 (backward-data, on v_mfma_f32_32x32x2_f32)', 1.0),
+            # the Winograd slots account EXECUTED FLOPs (2 * M * C * 16 per 2x2 output tile = the direct sum's / 2.25)
+            'conv_wino_fwd': ('k_conv_wino (forward of the 3x3 stride-1 data convolutions: Winograd F(2x2, 3x3) around '
+                              'v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv_wino_dgrad': ('k_conv_wino (backward-data of the 3x3 stride-1 data convolutions: Winograd F(2x2, 3x3) around '
+                                'v_mfma_f32_32x32x2_f32)', 1.0)}
         rms, rn = prof.get('conv_wgrad_reduce', (0.0, 0))
         mfma, mfma_all = None, {}
         for slot, (what, issued) in MFMA_SLOTS.items():
@@ -714,6 +719,11 @@ def main():
                    'launches_per_step': round(n / sampled, 1), 'us_per_step': round(1000.0 * ms / sampled, 1),
                    'note': 'algorithmic FLOPs = 2 * Co * Ci * taps * N * OH * OW per launch (SURVEY.md 8(d)), summed over the '
                            'timed launches / their summed kernel time; `achieved` = the FLOPs the matrix cores execute'}
+            if slot.startswith('conv_wino'):
+                rec['direct_equivalent_TFLOPs'] = round(2.25 * tf, 1)
+                rec['note'] = ('EXECUTED FLOPs = 2 * M * C * 16 * N * (H / 2) * (W / 2) per launch: F(2x2, 3x3) spends 16 MFMA '
+                               'multiplies where the direct sum spends 36 (direct_equivalent_TFLOPs = the rate a direct kernel '
+                               'would need for the same launch time; it may exceed the fp32 MFMA peak)')
             if issued > 1:
                 rec['algorithmic_over_fp32_mfma_peak'] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
                 rec['note'] += (' (6 bf16 MFMA products per fp32 product) against the dense bf16 peak; the algorithmic rate is '

@@ -1,0 +1,31 @@
+// deepipr_conv_plan.h -- internal (not installed): what the two translation units of libdeepipr_hip.so share about the
+// forward / backward-data convolution kernels.  deepipr_hip.hip holds the C ABI and every other kernel; deepipr_wino.hip
+// holds the Winograd kernels and is compiled with -fno-slp-vectorize (the SLP vectoriser packs the transforms' scalar fp32
+// adds into v_pk_* instructions that need register shuffles to feed: +30 vector instructions per chunk beside the MFMAs).
+#ifndef DEEPIPR_CONV_PLAN_H
+#define DEEPIPR_CONV_PLAN_H
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+#define DIPR_HIDDEN __attribute__((visibility("hidden")))
+
+struct FwPlan {
+    int cfg;        // 0: unsupported; >= 1000: a Winograd instance (1000 + width code * 100 + m blocks * 10 + k groups)
+    int bands;      // row bands per image group
+    int grid;       // output tiles (workgroups of the plain form)
+    int splits;     // K splits (1: plain)
+    int cps;        // chunks of CK channels per split
+    size_t slab;    // floats of one partial output
+};
+
+DIPR_HIDDEN int dipr_device_cu_count();
+// H, W: the map (stride 1, pad 1: input and output alike); C: input channels of the GEMM, M: output channels
+DIPR_HIDDEN FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride, int pad);
+// Enqueues k_conv_wino for plan `p` (ws != nullptr: split K, slab `split` of ws takes the partial output).  ev_a / ev_b: the
+// dispatch's own start / stop events when the caller times it (both or neither).  -> false: no instance for p.cfg.
+DIPR_HIDDEN bool dipr_launch_conv_wino(const FwPlan &p, bool dgrad, const float *wgt, const float *in, float *out, int N, int Cin,
+                                       int M, int H, float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b);
+#ifdef DEEPIPR_TRACE
+DIPR_HIDDEN bool dipr_wino_set_trace(unsigned long long *device_buffer);
+#endif
+#endif

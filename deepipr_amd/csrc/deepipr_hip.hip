@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/deepipr_hip.h"
+#include "deepipr_conv_plan.h"
 
 namespace {
 
@@ -4069,7 +4070,6 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
 namespace {
 #include "deepipr_conv.inc"
 #include "deepipr_conv_fwd.inc"
-#include "deepipr_conv_wino.inc"
 
 template <class C>
 void launch_wgrad(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
@@ -4212,19 +4212,10 @@ int conv_algo() {
 // the plan a 3x3 / 1x1 forward-shaped GEMM call takes: Winograd where it applies and is switched on, else the direct form
 FwPlan plan_conv_any(int N, int C, int M, int H, int W, int k, int stride, int pad) {
     if (conv_algo() == 1) {
-        const FwPlan p = plan_conv_wino(N, C, M, H, W, k, stride, pad);
+        const FwPlan p = dipr_plan_conv_wino(N, C, M, H, W, k, stride, pad);
         if (p.cfg) return p;
     }
     return plan_conv_gemm(N, C, M, H, W, k, stride, pad);
-}
-
-template <class C, bool DGRAD>
-void launch_wino(ProfScope &prof, const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H,
-                 hipStream_t st, float *ws) {
-    if (ws) DEEPIPR_LAUNCH(prof, (k_conv_wino<C, DGRAD>), dim3(p.grid * p.splits), dim3(C::NTH), st, wgt, in, out, N, Cin, M, H,
-                           p.bands, ws, p.grid, p.cps, p.slab);
-    else DEEPIPR_LAUNCH(prof, (k_conv_wino<C, DGRAD>), dim3(p.grid), dim3(C::NTH), st, wgt, in, out, N, Cin, M, H, p.bands,
-                        static_cast<float *>(nullptr), p.grid, Cin, p.slab);
 }
 
 template <bool DGRAD>
@@ -4232,37 +4223,22 @@ int conv_wino(const FwPlan &p, const float *wgt, const float *in, float *out, in
               hipStream_t st, const char *what, void *workspace, size_t workspace_bytes) {
     if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))
         return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
+    // split K needs its slabs: without a workspace one workgroup walks all of K
     float *ws = (p.splits > 1 && workspace && workspace_bytes >= p.splits * p.slab * sizeof(float)) ? static_cast<float *>(workspace) : nullptr;
-    FwPlan q = p;
-    if (p.splits > 1 && !ws) {                                 // no workspace: one workgroup walks all of K
-        q.splits = 1;
-        q.cps = Cin / 8;
-    }
     {
         ProfScope prof(DGRAD ? DEEPIPR_K_CONV_WINO_DGRAD : DEEPIPR_K_CONV_WINO_FWD, st);
         prof.bytes = 2.0 * M * Cin * 16.0 * static_cast<double>(N) * (H / 2) * (W / 2);          // EXECUTED FLOPs (direct: x 2.25)
-#define DEEPIPR_WINO(WW, TBR, NIB)                                                                                    \
-    switch (q.cfg % 100) {                                                                                            \
-        case 21: launch_wino<WnCfg<WW, TBR, NIB, 2, 1>, DGRAD>(prof, q, wgt, in, out, N, Cin, M, H, st, ws); break;   \
-        case 22: launch_wino<WnCfg<WW, TBR, NIB, 2, 2>, DGRAD>(prof, q, wgt, in, out, N, Cin, M, H, st, ws); break;   \
-        case 11: launch_wino<WnCfg<WW, TBR, NIB, 1, 1>, DGRAD>(prof, q, wgt, in, out, N, Cin, M, H, st, ws); break;   \
-        case 12: launch_wino<WnCfg<WW, TBR, NIB, 1, 2>, DGRAD>(prof, q, wgt, in, out, N, Cin, M, H, st, ws); break;   \
-        default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);                                          \
-    }
-        switch ((q.cfg / 100) % 10) {
-            case 3: DEEPIPR_WINO(32, 2, 1) break;
-            case 2: DEEPIPR_WINO(16, 4, 1) break;
-            case 1: DEEPIPR_WINO(8, 4, 2) break;
-            default: DEEPIPR_WINO(4, 2, 8) break;
-        }
-#undef DEEPIPR_WINO
+        const bool timed = prof.a && !prof.used;
+        if (!dipr_launch_conv_wino(p, DGRAD, wgt, in, out, N, Cin, M, H, ws, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))
+            return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
+        if (timed) prof.used = true;
     }
     if (ws) {
         ProfScope prof(DEEPIPR_K_CONV_SPLIT_SUM, st);
-        prof.bytes = 4.0 * (q.splits + 1.0) * q.slab;
-        const size_t n4 = q.slab / 4;
+        prof.bytes = 4.0 * (p.splits + 1.0) * p.slab;
+        const size_t n4 = p.slab / 4;
         DEEPIPR_LAUNCH(prof, k_conv_sum_slabs, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), st,
-                       reinterpret_cast<const f32x4 *>(ws), reinterpret_cast<f32x4 *>(out), n4, q.splits);
+                       reinterpret_cast<const f32x4 *>(ws), reinterpret_cast<f32x4 *>(out), n4, p.splits);
     }
     return check_launch(what);
 }
@@ -4368,10 +4344,9 @@ int deepipr_conv_set_algo(int algo) {
 int deepipr_conv_get_algo(void) { return conv_algo(); }
 
 #ifdef DEEPIPR_TRACE
-// measurement build only: device buffer of 10 u64 per workgroup for the Winograd kernels' phase stamps (nullptr: off)
+// measurement build only: device buffer of 64 u64 per workgroup for the Winograd kernels' phase stamps (nullptr: off)
 int deepipr_debug_wino_trace(unsigned long long *device_buffer) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &device_buffer, sizeof(device_buffer)) == hipSuccess
-               ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "debug_wino_trace: hipMemcpyToSymbol failed");
+    return dipr_wino_set_trace(device_buffer) ? DEEPIPR_OK : fail(DEEPIPR_ELAUNCH, "debug_wino_trace: hipMemcpyToSymbol failed");
 }
 #endif
 
@@ -4408,3 +4383,6 @@ int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
 }
 
 }  // extern "C"
+
+
+int dipr_device_cu_count() { return device_cu_count(); }

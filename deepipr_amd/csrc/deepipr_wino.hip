@@ -1,0 +1,65 @@
+// deepipr_wino.hip -- second translation unit of libdeepipr_hip.so: the Winograd F(2x2, 3x3) forward / backward-data kernels
+// (deepipr_conv_wino.inc), their planner and launcher.  Built with -fno-slp-vectorize (Makefile; deepipr_conv_plan.h says why).
+// The C ABI entry points that reach this code are in deepipr_hip.hip (deepipr_conv_fwd_ws / deepipr_conv_dgrad_ws).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "deepipr_conv_plan.h"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+inline int device_cu_count() { return dipr_device_cu_count(); }
+#include "deepipr_conv_wino.inc"
+
+template <class C, bool DGRAD>
+void launch(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, float *ws, hipStream_t st,
+            hipEvent_t a, hipEvent_t b) {
+    const dim3 grid(ws ? p.grid * p.splits : p.grid), block(C::NTH);
+    const int cps = ws ? p.cps : Cin / C::CK;
+    if (a) hipExtLaunchKernelGGL((k_conv_wino<C, DGRAD>), grid, block, 0, st, a, b, 0, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid,
+                                 cps, p.slab);
+    else hipLaunchKernelGGL((k_conv_wino<C, DGRAD>), grid, block, 0, st, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid, cps, p.slab);
+}
+
+template <bool DGRAD>
+bool dispatch(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, float *ws, hipStream_t st,
+              hipEvent_t a, hipEvent_t b) {
+#define DIPR_WINO(WW, TBR, NIB)                                                                                       \
+    switch (p.cfg % 100) {                                                                                            \
+        case 21: launch<WnCfg<WW, TBR, NIB, 2, 1>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 22: launch<WnCfg<WW, TBR, NIB, 2, 2>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 11: launch<WnCfg<WW, TBR, NIB, 1, 1>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 12: launch<WnCfg<WW, TBR, NIB, 1, 2>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        default: return false;                                                                                        \
+    }
+    switch ((p.cfg / 100) % 10) {
+        case 3: DIPR_WINO(32, 2, 1)
+        case 2: DIPR_WINO(16, 4, 1)
+        case 1: DIPR_WINO(8, 4, 2)
+        case 0: DIPR_WINO(4, 2, 8)
+        default: return false;
+    }
+#undef DIPR_WINO
+}
+}  // namespace
+
+FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride, int pad) {
+    return plan_conv_wino(N, C, M, H, W, k, stride, pad);
+}
+
+bool dipr_launch_conv_wino(const FwPlan &p, bool dgrad, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H,
+                           float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b) {
+    if (p.cfg < 1000) return false;
+    return dgrad ? dispatch<true>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b)
+                 : dispatch<false>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b);
+}
+
+#ifdef DEEPIPR_TRACE
+bool dipr_wino_set_trace(unsigned long long *device_buffer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &device_buffer, sizeof(device_buffer)) == hipSuccess;
+}
+#endif

@@ -967,6 +967,8 @@ def _own_fwd(x_in, w, stride, pad):
     n, ci, h, wd = x_in.shape
     if not kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0):
         return False
+    if kernels.conv_is_winograd(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0):
+        return True                                   # 3x3 stride 1: the Winograd kernel beats both the direct one and the library
     return _own_policy(n, h, wd, w.shape[2], stride) or _own_split(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 0)
 
 
@@ -976,6 +978,8 @@ def _own_dgrad(x_shape, w, stride, pad, dy):
     n, ci, h, wd = x_shape
     if not kernels.conv_supported(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1):
         return False
+    if kernels.conv_is_winograd(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1):
+        return True
     return (_own_policy(n, h, wd, w.shape[2], stride, backward_data=True)
             or _own_split(n, ci, w.shape[0], h, wd, w.shape[2], stride, pad, 1))
 
@@ -1069,6 +1073,11 @@ class _Conv2dOwn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+_nnmod = torch.nn.modules.module
+_GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS = _nnmod._global_forward_hooks, _nnmod._global_forward_pre_hooks
+_GLOBAL_BWD_HOOKS, _GLOBAL_BWD_PRE_HOOKS = _nnmod._global_backward_hooks, _nnmod._global_backward_pre_hooks
+
+
 def conv2d(conv, x):
     """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked for which this library has a kernel in at least one
     direction goes through _Conv2dOwn; anything else is the module call."""
@@ -1077,9 +1086,12 @@ def conv2d(conv, x):
             and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
             and conv.kernel_size[0] == conv.kernel_size[1]
             and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or conv._backward_pre_hooks)
+            and not (_GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS or _GLOBAL_BWD_HOOKS or _GLOBAL_BWD_PRE_HOOKS)   # Module.__call__ runs them
+            and not torch.is_autocast_enabled()
             and type(conv) is torch.nn.Conv2d and 'forward' not in conv.__dict__):     # nor wrapped its forward
         st, pd, w = conv.stride[0], conv.padding[0], conv.weight
-        if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)):
+        if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)
+                or (torch.is_grad_enabled() and x.requires_grad and _own_dgrad(x.shape, w, st, pd, x))):
             return _Conv2dOwn.apply(x, w, st, pd)
     return conv(x)
 

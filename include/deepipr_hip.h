@@ -279,6 +279,11 @@ int deepipr_debug_tune(const char *key, int value);
  * workgroup sums formed, exchange done, channel table ready, all stores issued.  The buffer needs 8 * 8 bytes per
  * workgroup (<= 2 * CUs + 1 of them); pass NULL to switch tracing off. */
 int deepipr_debug_trace(unsigned long long *device_buffer);
+/* The same for the Winograd convolution kernels (k_conv_wino): thread 0 of every workgroup writes {100 MHz wall clock,
+ * shader clock} pairs to device_buffer[block][32][2]: 0 entry, 1 first chunk staged, 2 MFMA loop done, 3 transformed
+ * sums in LDS, 4 stores issued, then for the first nine chunks: step top, LDS writes drained, barrier passed
+ * (tools/wino_trace.py).  64 * 8 bytes per workgroup; NULL switches it off. */
+int deepipr_debug_wino_trace(unsigned long long *device_buffer);
 #endif
 int deepipr_passport_bn_resident(int N, int C, int HW, int have_sync);
 /* Workgroups per channel the single-pass kernels would use for this shape when exchange words are passed (the larger

@@ -12,9 +12,13 @@ DEV = 'cuda:0'
 
 @pytest.fixture(scope='module')
 def K():
+    """This module pins the DIRECT implicit-GEMM family (the stride-1 3x3 instances are what every shape outside the Winograd
+    kernels' reach takes, and what DEEPIPR_CONV_ALGO=direct selects); tests/test_conv_wino_gpu.py covers the default."""
     from deepipr_amd.passport_ops import kernels
     assert torch.cuda.is_available(), 'needs an MI355X'
-    return kernels
+    before = kernels.set_conv_algo('direct')
+    yield kernels
+    kernels.set_conv_algo(before)
 
 
 def _rand(shape, seed, scale=1.0):
@@ -140,6 +144,7 @@ def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
     from deepipr_amd import _lib
     from deepipr_amd import passport_ops as P
     from deepipr_amd.models.resnet_passport import BasicPassportBlock
+    K.set_conv_algo('winograd')                                 # the library default (the fixture restores its own setting)
     kw = {name: {'flag': False, 'norm_type': 'bn'} for name in ('convbnrelu_1', 'convbn_2', 'shortcut')}
     res = {}
     for mode in ('all', 'auto', '0'):
@@ -155,9 +160,12 @@ def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
         _lib.profile_enable(False)
         prof = _lib.profile_read()
         res[mode] = (y.detach(), x.grad, [p.grad for p in blk.parameters()],
-                     (int(prof['conv_fwd'][1]), int(prof['conv_dgrad'][1]),
+                     (int(prof['conv_fwd'][1]) + int(prof['conv_wino_fwd'][1]),          # direct + Winograd instances
+                      int(prof['conv_dgrad'][1]) + int(prof['conv_wino_dgrad'][1]),
                       int(prof['conv_wgrad'][1]) + int(prof['conv_wgrad_b3'][1])))     # fp32-MFMA + bf16x3 instances
-    assert res['all'][3] == (3, 3, 3) and res['auto'][3] == (2, 2, 3) and res['0'][3] == (0, 0, 0)
+    # auto: the stride-1 3x3 takes the Winograd kernel at any size (round 5; the direct kernel needed >= 32 768 positions)
+    assert res['all'][3] == (3, 3, 3) and res['auto'][3] == (3, 3, 3) and res['0'][3] == (0, 0, 0)
+    K.set_conv_algo('direct')
     for mode in ('all', 'auto'):
         for a, b in zip([res[mode][0], res[mode][1]] + res[mode][2], [res['0'][0], res['0'][1]] + res['0'][2]):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9

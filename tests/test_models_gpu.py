@@ -248,42 +248,16 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
     def ref_forward():
         return [ref(x64) if i is None else ref(x64, ind=i) for i in inds]
 
-    # ---- pass 1: where are the kinks (float64, no grad; the norm buffers are restored afterwards)
-    state = {'current': None, 'near': {}}
+    # ---- pass 1: where are the kinks (float64, no grad; the norm buffers are restored afterwards).  Gating an element changes
+    # what the later layers see (their batch statistics move by a few 1e-7), so an element that sat just outside the band in
+    # the un-gated net can sit inside it in the gated one: the search is repeated ON THE GATED NET until it finds nothing new
+    # (round 5: with the Winograd kernels' roundings the AlexNet case flipped such an element -- 1.1e-4 from its kink
+    # un-gated, inside the band gated -- and every gradient upstream of it moved by 3e-4).
     ref_layers = _layer_modules(ref, (torch_ref.ConvBlockRef, torch_ref.PassportLayerRef))
     saved = {k: v.clone() for k, v in ref.state_dict().items()}
-    hooks = []
-    for name, m in ref_layers:
-        hooks.append(m.register_forward_pre_hook(lambda _m, _i, name=name: state.__setitem__('current', name)))
-        hooks.append(m.register_forward_hook(lambda _m, _i, _o: state.__setitem__('current', None)))
     # max-pool layers (AlexNet): a window whose two largest entries lie within `tol` may route its gradient to either
     pools = [(k, m) for k, m in ref.named_modules() if isinstance(m, torch.nn.MaxPool2d)]
-    ties = {}
 
-    def tie_hook(name):
-        def hook(m, inp, out):
-            ks = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
-            win = torch.nn.functional.unfold(inp[0].reshape(-1, 1, *inp[0].shape[2:]), ks, stride=m.stride, padding=m.padding)
-            top2 = win.topk(2, dim=1).values
-            ties.setdefault(name, []).append(((top2[:, 0] - top2[:, 1]) < tol).reshape(out.shape))
-        return hook
-    for name, m in pools:
-        hooks.append(m.register_forward_hook(tie_hook(name)))
-    monkeypatch.setattr(torch_ref, 'F', _RecordingF(state, tol))
-    with torch.no_grad():
-        ref_forward()
-    monkeypatch.undo()
-    monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
-    for h in hooks:
-        h.remove()
-    ref.load_state_dict(saved)
-    near = state['near']
-    assert set(near) == {k for k, _ in ref_layers} and all(len(v) == len(inds) for v in near.values())
-    gated = sum(int(t.sum()) for v in near.values() for t in v)
-    total = sum(t.numel() for v in near.values() for t in v)
-    assert 0 < gated < 2e-3 * total, (gated, total)
-
-    # ---- pass 2: both nets with the near-kink outputs gated
     def gate(masks, dtype):
         calls = {'n': 0}
 
@@ -294,6 +268,55 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
                 return tuple(o * keep for o in out)
             return out * keep
         return hook
+
+    def tie_hook(found, name):
+        def hook(m, inp, out):
+            ks = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            win = torch.nn.functional.unfold(inp[0].reshape(-1, 1, *inp[0].shape[2:]), ks, stride=m.stride, padding=m.padding)
+            top2 = win.topk(2, dim=1).values
+            found.setdefault(name, []).append(((top2[:, 0] - top2[:, 1]) < tol).reshape(out.shape))
+        return hook
+
+    near, ties, rounds = {}, {}, 0
+    real_f = torch_ref.F
+    while True:
+        state = {'current': None, 'near': {}}
+        found_ties, hooks = {}, []
+        for name, m in ref_layers:
+            hooks.append(m.register_forward_pre_hook(lambda _m, _i, name=name: state.__setitem__('current', name)))
+            hooks.append(m.register_forward_hook(lambda _m, _i, _o: state.__setitem__('current', None)))
+            if near:
+                hooks.append(m.register_forward_hook(gate(near[name], torch.float64)))
+        for name, m in pools:
+            hooks.append(m.register_forward_hook(tie_hook(found_ties, name)))
+            if ties:
+                hooks.append(m.register_forward_hook(gate(ties[name], torch.float64)))
+        torch_ref.F = _RecordingF(state, tol)
+        try:
+            with torch.no_grad():
+                ref_forward()
+        finally:
+            torch_ref.F = real_f
+            for h in hooks:
+                h.remove()
+            ref.load_state_dict(saved)
+        added = 0
+        for table, fresh in ((near, state['near']), (ties, found_ties)):
+            for k, masks in fresh.items():
+                old = table.get(k)
+                merged = masks if old is None else [a | b for a, b in zip(old, masks)]
+                added += sum(int(m.sum()) for m in merged) - (0 if old is None else sum(int(m.sum()) for m in old))
+                table[k] = merged
+        rounds += 1
+        if rounds > 1 and added == 0:
+            break
+        assert rounds < 8, 'the near-kink search does not settle'
+    assert set(near) == {k for k, _ in ref_layers} and all(len(v) == len(inds) for v in near.values())
+    gated = sum(int(t.sum()) for v in near.values() for t in v)
+    total = sum(t.numel() for v in near.values() for t in v)
+    assert 0 < gated < 2e-3 * total, (gated, total)
+
+    # ---- pass 2: both nets with the near-kink outputs gated
     for name, m in ref_layers:
         m.register_forward_hook(gate(near[name], torch.float64))
     prod_pools = dict((k, m) for k, m in prod.named_modules() if isinstance(m, torch.nn.MaxPool2d))
@@ -341,15 +364,15 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
     assert abs(float(loss_p) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
     assert abs(float(sign_p) - float(sign_r)) <= 1e-4 * max(1.0, abs(float(sign_r)))
     gp = dict(prod.named_parameters())
-    worst = (0.0, None)
+    errs = []
     for name, p in ref.named_parameters():
         assert p.grad is not None and gp[name].grad is not None, name
         scale = float(p.grad.abs().max()) + 1e-30
-        rel = float((gp[name].grad.double() - p.grad).abs().max()) / scale
-        worst = max(worst, (rel, name))
-        assert rel <= 1e-4, (name, rel, scale)
-    print('whole-net backward, kinks gated (%d of %d activations): worst gradient error %.2e of scale (%s)'
-          % (gated, total, worst[0], worst[1]))
+        errs.append((float((gp[name].grad.double() - p.grad).abs().max()) / scale, name))
+    worst = max(errs)
+    assert worst[0] <= 1e-4, sorted(errs, reverse=True)[:8]
+    print('whole-net backward, kinks gated (%d of %d activations, %d search rounds): worst gradient error %.2e of scale (%s)'
+          % (gated, total, rounds, worst[0], worst[1]))
 
 
 # ----------------------------------------------------------------------------- shared trunk of the V2 / V3 dual forward

@@ -22,7 +22,7 @@ dev = torch.device('cuda:0')
 def run(n, c, hw, direction):
     x = torch.randn(n, c, hw, hw, device=dev)
     w = torch.randn(c, c, 3, 3, device=dev) * 0.05
-    buf = torch.zeros(10 * 8192, dtype=torch.int64, device=dev)
+    buf = torch.zeros(64 * 8192, dtype=torch.int64, device=dev)
     fn = (lambda: K.conv_fwd(x, w, 1, 1)) if direction == 0 else (lambda: K.conv_dgrad(x, w, x.shape, 1, 1))
     for _ in range(3):
         fn()
@@ -35,10 +35,10 @@ def run(n, c, hw, direction):
     _lib.lib().deepipr_debug_wino_trace(None)
     prof = _lib.profile_read()
     us = 1000.0 * sum(prof[k][0] for k in ('conv_wino_fwd', 'conv_wino_dgrad'))
-    t = buf.view(-1, 5, 2).cpu().numpy().astype(np.int64)
+    t = buf.view(-1, 32, 2).cpu().numpy().astype(np.int64)
     t = t[t[:, 0, 0] > 0]
     wall = (t[:, :, 0] - t[:, 0, 0].min()) * 0.01              # us since the first workgroup's entry
-    cyc = np.diff(t[:, :, 1], axis=1)                           # shader cycles per phase
+    cyc = np.diff(t[:, :5, 1], axis=1)                           # shader cycles per phase
     names = ['prologue', 'mfma_loop', 'park', 'store']
     line = '%4d x %3d @%2d %s: %6.1f us, %4d wgs, start skew %5.1f us, last end %5.1f us |' % (
         n, c, hw, 'fwd' if direction == 0 else 'dgr', us, len(t), wall[:, 0].max(), wall[:, 4].max())
@@ -48,6 +48,12 @@ def run(n, c, hw, direction):
     line += ' | %5.0f cyc/chunk' % (cyc[:, 1].mean() / max(1, chunks))
     line += ' | wall: loop starts %5.1f..%5.1f, ends %5.1f..%5.1f' % (wall[:, 1].min(), wall[:, 1].max(), wall[:, 2].min(), wall[:, 2].max())
     print(line, flush=True)
+    steps = min(9, chunks)
+    st = t[:, 5:5 + 3 * steps, 1].reshape(len(t), steps, 3)
+    body, bar = (st[:, :, 1] - st[:, :, 0]), (st[:, :, 2] - st[:, :, 1])
+    gap = st[:, 1:, 0] - st[:, :-1, 2]
+    print('      per step (cycles, mean over workgroups): body', np.round(body.mean(0)).astype(int).tolist(), 'barrier wait', np.round(bar.mean(0)).astype(int).tolist(),
+          'gap', np.round(gap.mean(0)).astype(int).tolist(), flush=True)
 
 
 for n, c, hw in SHAPES:
