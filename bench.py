@@ -126,6 +126,50 @@ def fused_layer_elements(model, run_once):
     return sizes, passport
 
 
+# The other BASELINE.json configurations that fit one GPU, measured in the SAME driver run as the headline (N = 1 only; a
+# bounded sub-run each, about 20 s with its find phase): one rank's shard of config 3 (V2, 100 classes, 32 images), config 4's
+# shard (V3: 64 images + the trigger pair) and config 1 (AlexNet V1, batch 64) on the GPU.
+OTHER_CONFIGS = [
+    ('P_shard', 'BASELINE configs[2], one rank of 8: ResNet18 V2 private, CIFAR100 shapes, 32 images per GPU',
+     ['--scheme', '2', '--classes', '100', '--batch', '32']),
+    ('V3_shard', 'BASELINE configs[3], one rank of 4: ResNet18 V3 (V2 + trigger pair), CIFAR100 shapes, 64 + 2 images per GPU',
+     ['--scheme', '3', '--classes', '100', '--batch', '64']),
+    ('AlexNet_A', 'BASELINE configs[0] on the GPU: AlexNet V1 passport, CIFAR10 shapes, batch 64',
+     ['--arch', 'alexnet', '--batch', '64']),
+]
+
+
+def is_headline(args):
+    return (args.arch == 'resnet18' and args.scheme == 1 and args.batch == 128 and args.image_size == 32 and args.classes == 10
+            and args.norm_type == 'bn' and not (args.eager or args.ddp or args.no_fuse))
+
+
+def other_configs(steps=60, warmup=15, timeout=150):
+    import subprocess
+    res = {}
+    for key, what, flags in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline',
+               '--no-stress', '--no-configs'] + flags
+        t0 = time.perf_counter()
+        try:
+            run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+            line = [ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            rec = {'what': what, 'flags': ' '.join(flags), 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                   'steps': d['steps'], 'warmup': d['warmup'], 'sign_detect_acc': d.get('sign_detect_acc'),
+                   'exchange_timeouts': d.get('exchange_timeouts'), 'workload': d['config']['workload'],
+                   'wall_s': round(time.perf_counter() - t0, 1)}
+            for k in ('roofline', 'roofline_passport'):
+                if k in d:
+                    r = {kk: vv for kk, vv in d[k].items() if kk not in ('kernels', 'note', 'traffic_source')}
+                    r['kernel'] = str(r.get('kernel', ''))[:160]
+                    rec[k] = r
+            res[key] = rec
+        except Exception as e:                               # a sub-run must never take the headline line down
+            res[key] = {'what': what, 'flags': ' '.join(flags), 'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+    return res
+
+
 def host_cores():
     """CPUs this process may actually use: min(affinity, cgroup cpu.max quota), capped at 32."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -301,6 +345,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-stress', action='store_true', help='skip the stress-shape roofline measurement')
+    ap.add_argument('--no-configs', action='store_true', help="skip the other BASELINE configurations' lines (`configs` block)")
     ap.add_argument('--graph', action='store_true', help='hipGraph replay of the step (the default; kept for compatibility)')
     ap.add_argument('--eager', action='store_true', help='eager dispatch of the timed region (exchange overlapped with backward)')
     ap.add_argument('--ddp', action='store_true', help='DistributedDataParallel + torch fused SGD instead of FlatSGD')
@@ -778,6 +823,9 @@ def main():
             out['roofline_stress']['traffic'] = pmc_traffic(out['roofline_stress']['kernel'], 'S3[512,512,8,8]')
     if args.gpus == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
+    # only the full default line carries them: the lean forms the tools use (--no-stress / --no-cpu-baseline, rocprofv3 runs) do not
+    if args.gpus == 1 and not (args.no_configs or args.no_stress or args.no_cpu_baseline) and is_headline(args):
+        out['configs'] = other_configs()
     print(json.dumps(out), flush=True)
     _leave()
 

@@ -197,12 +197,15 @@ class PassportLayerBase(nn.Module):
         self._pooled.clear()                       # the keys were refilled in place
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, x, force_passport, ind, residual=None, conv_out=None):
+    def _forward(self, x, force_passport, ind, residual=None, conv_out=None, stack=None):
         """The layer; with `residual` (the shortcut of a residual block whose last layer this is) the pair of handles
         of relu(layer(x) + residual), folded into the layer's own kernels when they take the single-pass form.
         conv_out: self.conv(x), already computed by the caller (the two branches of a V2 / V3 dual forward share the
         data convolution of the first layers behind the point where they part: same input, same weight)."""
-        y = self._layer(x, force_passport, ind, residual, conv_out)
+        if stack is not None:                        # stacked branches (passport_ops.StackShare): the caller checked stackable()
+            y = self._layer(x, force_passport, ind, residual, conv_out, stack)
+        else:
+            y = self._layer(x, force_passport, ind, residual, conv_out)     # (the signature tests and attack scripts wrap)
         if residual is None or isinstance(y, tuple):
             return y
         return P.add_relu_fork(y, residual)
@@ -254,7 +257,17 @@ class PassportLayerBase(nn.Module):
         return (x.dim() == 4 and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks
                 and not self._forward_hooks and not self._forward_pre_hooks)
 
-    def _layer(self, x, force_passport, ind, residual, conv_out=None):
+    def stackable(self, x):
+        """The two branches of a dual forward may run this layer in lockstep on halves of one buffer
+        (passport_ops.StackShare): both branches take the fused BatchNorm form (learnable scale AND bias on the public one),
+        around a plain un-hooked convolution the caller may run once for both."""
+        c = self.conv
+        return (self.scale is not None and self.bias is not None and self.fuse_norm and P.bn_is_fusable(self.bn)
+                and x.is_cuda and x.dtype == torch.float32 and self.shareable_conv(x) and self._conv_inside(x)
+                and type(c) is nn.Conv2d and c.kernel_size[0] == c.kernel_size[1] and c.stride[0] == c.stride[1]
+                and isinstance(c.padding, tuple) and c.padding[0] == c.padding[1])
+
+    def _layer(self, x, force_passport, ind, residual, conv_out=None, stack=None):
         self.ensure_key(x)
         relu = self.relu is not None
         p_scale = self._use_param(self.scale, force_passport, ind)
@@ -273,7 +286,7 @@ class PassportLayerBase(nn.Module):
             x = P.conv2d(self.conv, x)
         if public:                                   # learnable scale / bias, no sign loss
             if form == 'bn':
-                return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail)
+                return P.bn_affine_relu(x, self.scale, self.bias, self.bn, relu, tail, stack=stack)
             if form == 'gn':
                 return P.gn_affine_relu(x, self.scale, self.bias, self.bn, relu)
             return P.affine_relu(self.bn(x), self.scale, self.bias, relu)
@@ -285,7 +298,8 @@ class PassportLayerBase(nn.Module):
         if form == 'bn':
             pre, self._gb_pre = self._gb_pre, None   # gamma / beta from the net's batched GEMV launch, if any
             y, gamma, _beta, loss, acc, _bits = P.passport_bn_layer(
-                x, self.weight, skey, key, b, m, self.bn, alpha, relu, stride, pad, tail, conv_inside=inside, pre=pre)
+                x, self.weight, skey, key, b, m, self.bn, alpha, relu, stride, pad, tail, conv_inside=inside, pre=pre,
+                stack=stack)
         elif form == 'gn':
             y, gamma, _beta, loss, acc, _bits = P.passport_gn_layer(
                 x, self.weight, skey, key, b, m, self.bn, alpha, relu, stride, pad, conv_inside=inside)

@@ -14,8 +14,8 @@ class PassportPrivateBlock(PassportLayerBase):
         self.init_public_bit = passport_kwargs.get('init_public_bit', True)     # stored, unused (:44)
         self._build(i, o, ks, s, pd, passport_kwargs, True, learnable_affine=True, always_sign_loss=True)
 
-    def forward(self, x, force_passport=False, ind=0, _residual=None, _conv_out=None):
-        return self._forward(x, force_passport, ind, _residual, _conv_out)
+    def forward(self, x, force_passport=False, ind=0, _residual=None, _conv_out=None, _stack=None):
+        return self._forward(x, force_passport, ind, _residual, _conv_out, _stack)
 
     def forward_tail(self, x, residual, force_passport=False, ind=0):
         """-> two handles of relu(self(x) + residual): this layer as the last one of a residual block."""

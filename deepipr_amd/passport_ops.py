@@ -447,7 +447,7 @@ class HipKernels:
         return dxa, dxb, d[0], d[1], d[2], d[3]
 
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
-                        momentum, eps, training, margin=MARGIN, l2=L2, residual=None, pre=False):
+                        momentum, eps, training, margin=MARGIN, l2=L2, residual=None, pre=False, out=None):
         """BatchNorm(affine=False) + passport affine + ReLU (+ sign loss) from the conv output x; with `residual`
         (single-pass shapes only) y = relu(that + residual), the tail of a residual block.
         pre=True: gamma_in / beta_in ARE the passport gamma / beta of `weight` (computed by the net's batched GEMV
@@ -460,7 +460,7 @@ class HipKernels:
         hw = x.numel() // (n * c)
         lib = _lib.lib()
         st = _stream(dev)
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else out         # `out`: a dense tensor of x's shape (half of a StackShare buffer)
         # one small allocation: [table C*8 | gamma C | beta C | loss, acc] floats (+ bits as int8 when needed)
         small = torch.empty(c * 10 + 2, dtype=torch.float32, device=dev)
         base = small.data_ptr()
@@ -498,7 +498,7 @@ class HipKernels:
         return y, table, gamma, beta, loss, acc, bits
 
     def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
-                        margin=MARGIN, l2=L2, dy2=None, tail_out=None):
+                        margin=MARGIN, l2=L2, dy2=None, tail_out=None, dx_out=None, dres_out=None):
         """-> dx, dW (None when wshape is None), dgamma, dbeta [, dres when tail_out is given: the fused residual
         tail, dres = (dy + dy2) * [tail_out > 0] is the shortcut's gradient]."""
         dev = _chk(dy, x, dy2, tail_out)
@@ -508,11 +508,11 @@ class HipKernels:
         st = _stream(dev)
         nws = (self._bn_ws_bytes(n, c, hw) + 255) // 256 * 256
         scratch = self._scratch(dev, st, nws + 32 * c)          # partial sums | backward channel table
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if dx_out is None else dx_out
         dw = torch.empty(wshape, dtype=torch.float32, device=dev) if wshape is not None else None
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         pg = dgb.data_ptr()
-        dres = torch.empty_like(x) if tail_out is not None else None
+        dres = (torch.empty_like(x) if dres_out is None else dres_out) if tail_out is not None else None
         sync = self._sync_words(dev, st)
         if sync is not None and self.bn_slices(n, c, hw) > 1:
             self.sync_launches += 1
@@ -1036,6 +1036,91 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     return dx, dw, False
 
 
+class StackShare:
+    """The two branches of a V2 / V3 dual forward (trainer_private.py:159-171: model(x, ind=0) and model(x, ind=1) over the
+    same batch) as HALVES OF ONE BUFFER.  Behind the point where the branches part, the private passport layers convolve two
+    different inputs with the same weight; run in lockstep, that is ONE convolution of the 2N-image stack -- forward,
+    backward-data and weight gradient (which then already is the branches' sum) -- while the norm + affine kernels still
+    run per branch (their own batch statistics, the public branch's learnable scale / bias against the private branch's
+    passport gamma / beta).  One StackShare per layer call pair hands the branch nodes the halves to write -- forward
+    output, backward dx, the tail's shortcut gradient -- so that stacking and un-stacking never copy, and carries the
+    private branch's dgamma / dbeta to the stacked convolution's weight gradient, whose reduction pass adds the passport
+    branch's rank-2 term (deepipr_conv_wgrad): the shared weight's gradient is complete when it is first written."""
+    __slots__ = ('n', 'bufs', 'rank2')
+
+    def __init__(self, n):
+        self.n, self.bufs, self.rank2 = n, {}, None
+
+    def half(self, tag, b, like):
+        """Branch b's half ([n, ...] view) of the buffer `tag`, shaped and placed like the per-branch tensor `like`."""
+        buf = self.bufs.get(tag)
+        if buf is None:
+            buf = self.bufs[tag] = torch.empty((2 * self.n,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        return buf[b * self.n:(b + 1) * self.n]
+
+
+def _adjacent_halves(a, b):
+    """a and b are the two dense halves, in this order, of one allocation."""
+    return (a is not None and b is not None and a.shape == b.shape and a.dtype == b.dtype and a.device == b.device
+            and a.is_contiguous() and b.is_contiguous() and a.numel() > 0
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel())
+
+
+def _stack_pair(a, b):
+    """[a; b] along the batch: without a copy when they are adjacent halves of one buffer, torch.cat otherwise (None = zeros)."""
+    if a is None and b is None:
+        return None
+    if a is None:
+        a = torch.zeros_like(b)
+    if b is None:
+        b = torch.zeros_like(a)
+    if _adjacent_halves(a, b):
+        shape = (2 * a.shape[0],) + tuple(a.shape[1:])
+        return torch.empty(0, dtype=a.dtype, device=a.device).set_(a.untyped_storage(), a.storage_offset(), shape)
+    return torch.cat([a.contiguous(), b.contiguous()], dim=0)
+
+
+class _Unstack(torch.autograd.Function):
+    """[2N, ...] -> its two [N, ...] halves (views).  Backward puts the halves' gradients back together: no copy when the
+    branch nodes wrote them into the halves of one StackShare buffer."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.shape[0] // 2
+        ctx.set_materialize_grads(False)
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        return _stack_pair(g0, g1)
+
+
+class _Restack(torch.autograd.Function):
+    """(a, b) -> [a; b] along the batch (no copy for the halves of one StackShare buffer); backward hands the halves out."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
+        return _stack_pair(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        n = g.shape[0] // 2
+        g = g.contiguous()
+        return g[:n], g[n:]
+
+
+def unstack(x):
+    return _Unstack.apply(x.contiguous())
+
+
+def restack(a, b):
+    return _Restack.apply(a, b)
+
+
 class _Conv2dOwn(torch.autograd.Function):
     """`conv(x)` of a plain bias-free convolution (models/layers/conv2d.py:31; passportconv2d.py:218 when the data
     convolution runs outside the fused node) with this library's kernels wherever the policy above picks them -- forward
@@ -1043,10 +1128,11 @@ class _Conv2dOwn(torch.autograd.Function):
     for the rest, per direction."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, share=None):
         x, w = x.contiguous(), w.contiguous()
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad)
+        ctx.share = share                          # StackShare: may carry the private branch's (dgamma, dbeta, m) at backward time
         ctx.set_materialize_grads(False)
         return _conv_fwd(x, w, stride, pad)
 
@@ -1055,12 +1141,19 @@ class _Conv2dOwn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.geom
         if dy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         dy = dy.contiguous()
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
+        r2 = ctx.share.rank2 if ctx.share is not None else None     # the passport branch's rank-2 term rides in the wgrad
+        if ctx.share is not None:
+            ctx.share.rank2 = None
         if need_dw and _own_wgrad(x, w, stride, pad):
-            dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad)
+            if r2 is not None and w.shape[1] % 64 == 0:
+                dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad, *r2)
+                r2 = None
+            else:
+                dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad)
             need_dw = False
         if need_dx and _own_dgrad(x.shape, w, stride, pad, dy):
             dx = kernels.conv_dgrad(dy, w, x.shape, stride, pad)
@@ -1070,7 +1163,9 @@ class _Conv2dOwn(torch.autograd.Function):
                                                               [0, 0], 1, [need_dx, need_dw, False])
             dx = vdx if need_dx else dx
             dw = vdw if need_dw else dw
-        return dx, dw, None, None
+        if r2 is not None and dw is not None:
+            dw = kernels.gamma_beta_bwd_acc(r2[0], r2[1], r2[2], dw.contiguous())
+        return dx, dw, None, None, None
 
 
 _nnmod = torch.nn.modules.module
@@ -1078,9 +1173,11 @@ _GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS = _nnmod._global_forward_hooks, _nnmod.
 _GLOBAL_BWD_HOOKS, _GLOBAL_BWD_PRE_HOOKS = _nnmod._global_backward_hooks, _nnmod._global_backward_pre_hooks
 
 
-def conv2d(conv, x):
+def conv2d(conv, x, share=None):
     """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked for which this library has a kernel in at least one
-    direction goes through _Conv2dOwn; anything else is the module call."""
+    direction goes through _Conv2dOwn; anything else is the module call.  share: a StackShare whose private-branch node
+    leaves its dgamma / dbeta for this convolution's weight gradient (the caller has checked that the conv is a plain,
+    un-hooked one: PassportLayerBase.shareable_conv) -- always through _Conv2dOwn then."""
     if (OWN_CONV != '0' and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
             and conv.padding_mode == 'zeros' and conv.stride[0] == conv.stride[1]
             and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
@@ -1090,9 +1187,13 @@ def conv2d(conv, x):
             and not torch.is_autocast_enabled()
             and type(conv) is torch.nn.Conv2d and 'forward' not in conv.__dict__):     # nor wrapped its forward
         st, pd, w = conv.stride[0], conv.padding[0], conv.weight
+        if share is not None:
+            return _Conv2dOwn.apply(x, w, st, pd, share)
         if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)
                 or (torch.is_grad_enabled() and x.requires_grad and _own_dgrad(x.shape, w, st, pd, x))):
             return _Conv2dOwn.apply(x, w, st, pd)
+    if share is not None:
+        raise RuntimeError('deepipr_amd: conv2d(share=...) needs a plain bias-free square convolution on the GPU')
     return conv(x)
 
 
@@ -1210,6 +1311,7 @@ class _PassportBNLayer(torch.autograd.Function):
     def forward(ctx, x, weight, skey, key, gamma_in, beta_in, b, m, running_mean, running_var, nbt, residual, cfg):
         alpha, relu, stride, pad, training, momentum, eps, conv = cfg[:8]
         ctx.defer = cfg[8] if len(cfg) > 8 else None     # (Rank2Group share, index): see _Rank2Group
+        ctx.stack = stack = cfg[9] if len(cfg) > 9 else None     # (StackShare, branch, dx into the share?): see StackShare
         x = x.contiguous()
         w = None if weight is None else weight.contiguous()
         x_in = None
@@ -1224,7 +1326,8 @@ class _PassportBNLayer(torch.autograd.Function):
         # batched GEMV launch (gamma_beta_batch); backward is the passport branch's either way
         y, table, gamma, beta, loss, acc, bits = kernels.passport_bn_fwd(
             x, w, m, gi, bi, bb, float(alpha), relu, running_mean, running_var, nbt, float(momentum), float(eps),
-            training, residual=res, pre=(w is not None and gi is not None))
+            training, residual=res, pre=(w is not None and gi is not None),
+            out=None if stack is None else stack[0].half('y', stack[1], x))
         ctx.tail = res is not None
         ctx.save_for_backward(x, w, table, m, bb, y if ctx.tail else None, x_in)
         ctx.cfg = (float(alpha), relu, stride, pad, training, None if key is None else tuple(key.shape))
@@ -1255,14 +1358,21 @@ class _PassportBNLayer(torch.autograd.Function):
         if w is None:
             dgamma_extra = dbeta_extra = None
         in_node_conv = x_in is not None
+        stack = ctx.stack
+        # stacked branches: the rank-2 term of the private branch goes to the stacked convolution's weight gradient
+        to_conv = stack is not None and w is not None and not in_node_conv and ctx.needs_input_grad[1]
         # with the convolution inside this node the fresh dW is NOT written: the rank-2 update goes into MIOpen's
         # wgrad below (wshape None = "no dW" for the kernel; dgamma / dbeta still carry the sign-loss gradient)
         out = kernels.passport_bn_bwd(dy.contiguous(), x, table, m, bb, alpha, dl,
                                       _grad_or_none(dgamma_extra), _grad_or_none(dbeta_extra),
-                                      None if (w is None or in_node_conv) else w.shape, relu, training,
-                                      dy2=None if dy2 is None else dy2.contiguous(), tail_out=tail_out)
+                                      None if (w is None or in_node_conv or to_conv) else w.shape, relu, training,
+                                      dy2=None if dy2 is None else dy2.contiguous(), tail_out=tail_out,
+                                      dx_out=stack[0].half('dx', stack[1], x) if (stack is not None and stack[2]) else None,
+                                      dres_out=stack[0].half('dres', stack[1], x) if (stack is not None and ctx.tail) else None)
         dx, dw, dg, db = out[:4]
         dres = out[4] if ctx.tail else None
+        if to_conv:
+            stack[0].rank2 = (dg, db, m)
         deferred = False
         if in_node_conv:
             # the rank-2 update of several layers in ONE launch: this node hands MIOpen's wgrad and dgamma / dbeta to
@@ -1340,14 +1450,14 @@ def bn_dual_tail(xa, xb, bn_a, bn_b, relu_a=True, relu_b=True):
 
 
 def _bn_apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn, alpha, relu, stride, pad, residual, conv=None,
-              defer=None):
-    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps, conv, defer)
+              defer=None, stack=None):
+    cfg = (alpha, bool(relu), stride, pad, _bn_uses_batch_stats(bn), bn.momentum, bn.eps, conv, defer, stack)
     return _PassportBNLayer.apply(x, weight, skey, key, gamma_in, beta_in, b, m, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked if bn.training else None, residual, cfg)
 
 
 def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, residual=None, conv_inside=False,
-                      pre=None):
+                      pre=None, stack=None):
     """Fused passport branch on the conv output `x`; `bn` is the layer's nn.BatchNorm2d(affine=False).
     conv_inside: `x` is the layer's INPUT; the data convolution runs inside the node and the shared weight's
     gradient is accumulated in place (see _PassportBNLayer).
@@ -1357,7 +1467,7 @@ def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, 
     pg, pb = pre[:2] if pre is not None else (None, None)
     defer = tuple(pre[2:4]) if (pre is not None and len(pre) >= 4 and conv_inside) else None
     y, y2, gamma, beta, loss, acc, bits = _bn_apply(x, weight, skey, key, pg, pb, b, m, bn, alpha, relu, stride,
-                                                    pad, residual, (stride, pad) if conv_inside else None, defer)
+                                                    pad, residual, (stride, pad) if conv_inside else None, defer, stack)
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
@@ -1449,12 +1559,12 @@ def stage_groups(model):
     return group_of
 
 
-def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False):
+def bn_affine_relu(x, gamma, beta, bn, relu=True, residual=None, fork=False, stack=None):
     """Fused public branch: BatchNorm2d(affine=False) + learnable gamma/beta + ReLU; with `residual` the pair of
     handles of relu(that + residual).  fork=True hands the output out as a pair of handles as well (a layer whose
     output has two consumers without being a block's tail -- the CIFAR stem): the consumers' gradients then reach the
     backward kernel separately and are summed there instead of by an ATen add pass."""
-    out = _bn_apply(x, None, None, None, gamma, beta, None, None, bn, 0.0, relu, 1, 0, residual)
+    out = _bn_apply(x, None, None, None, gamma, beta, None, None, bn, 0.0, relu, 1, 0, residual, stack=stack)
     return (out[0], out[1]) if (residual is not None or fork) else out[0]
 
 

@@ -107,7 +107,7 @@ class OracleKernels:
         return 3                      # the host logic is exercised as if every shape took the single-pass form
 
     def passport_bn_fwd(self, x, weight, m, gamma_in, beta_in, b, alpha, relu, running_mean, running_var, nbt,
-                        momentum, eps, training, margin=npp.MARGIN, l2=npp.L2, residual=None, pre=False):
+                        momentum, eps, training, margin=npp.MARGIN, l2=npp.L2, residual=None, pre=False, out=None):
         x64 = x.detach().double()
         if training:
             mean = x64.mean(dim=(0, 2, 3))
@@ -133,12 +133,14 @@ class OracleKernels:
         table = torch.zeros(x.shape[1], 8)
         table[:, 0], table[:, 1], table[:, 2], table[:, 3] = mean.float(), invstd.float(), gamma, beta
         if b is None:
+            y = y if out is None else out.copy_(y)
             return y, table, (gamma if weight is not None else None), (beta if weight is not None else None), None, None, None
         loss, acc, bits = self.sign_loss_fwd(gamma, b, alpha, margin, l2)
+        y = y if out is None else out.copy_(y)
         return y, table, gamma, beta, loss, acc, bits
 
     def passport_bn_bwd(self, dy, x, table, m, b, alpha, dloss, dgamma_extra, dbeta_extra, wshape, relu, training,
-                        margin=npp.MARGIN, l2=npp.L2, dy2=None, tail_out=None):
+                        margin=npp.MARGIN, l2=npp.L2, dy2=None, tail_out=None, dx_out=None, dres_out=None):
         mean, invstd, gamma, beta = [table[:, i].double() for i in range(4)]
         dres = None
         if tail_out is not None:
@@ -164,8 +166,10 @@ class OracleKernels:
             dg = dg + self.sign_loss_bwd(dloss, table[:, 2].contiguous(), b, alpha, margin, l2)
         dw = self.gamma_beta_bwd(dg, db, m, wshape) if wshape is not None else None
         if tail_out is not None:
-            return dx.float(), dw, dg, db, dres
-        return dx.float(), dw, dg, db
+            dx = dx.float() if dx_out is None else dx_out.copy_(dx)
+            dres = dres if dres_out is None else dres_out.copy_(dres)
+            return dx, dw, dg, db, dres
+        return (dx.float() if dx_out is None else dx_out.copy_(dx)), dw, dg, db
 
     # ---- GroupNorm / InstanceNorm-fused entry points: float64 group statistics on the host as the checker ----
     def gn_supported(self, n, c, hw, groups):

@@ -337,8 +337,8 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
             gates[id(m)] = gate(near[name], torch.float32)
     inner = PassportLayerBase._layer
 
-    def gated_layer(self, x_in, force_passport, ind, residual, conv_out=None):
-        out = inner(self, x_in, force_passport, ind, residual, conv_out)
+    def gated_layer(self, x_in, force_passport, ind, residual, conv_out=None, stack=None):
+        out = inner(self, x_in, force_passport, ind, residual, conv_out, stack)
         g = gates.get(id(self))
         return out if g is None else g(self, None, out)
     monkeypatch.setattr(PassportLayerBase, '_layer', gated_layer)
@@ -395,6 +395,10 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
     x = torch.randn(32, 3, 32, 32, generator=g).to(DEV)
     y = torch.randint(0, 100, (32,), generator=g).to(DEV)
     res = {}
+    # this test is about the trunk: behind the split both modes run one pass per branch (the lockstep form convolves the 2N
+    # stack with another K split than the per-branch calls -- equal to rounding, not bit for bit; it has its own test below)
+    from deepipr_amd.models import resnet_passport as _rp
+    monkeypatch.setattr(_rp, '_STACKED', False)
     with pinned_miopen():
         for mode in ('shared', 'twice'):
             if mode == 'twice':
@@ -444,6 +448,67 @@ def test_shared_trunk_equals_two_full_passes_on_the_gpu(K, graph, monkeypatch):
             worst = float((a['state'][k] - v).abs().max())
             rel, ab = (5e-3, 2e-4) if graph else (1e-4, 5e-5)
             assert worst <= rel * float(v.abs().max()) + ab, (k, worst)
+
+
+@pytest.mark.parametrize('case', ['resnet18_bs32', 'resnet18_bs66', 'alexnet_bs64'])
+def test_stacked_branches_equal_one_pass_per_branch(K, case, monkeypatch):
+    """V2 / V3 dual forward: behind the point where the branches part, the private passport layers run both branches in
+    LOCKSTEP on halves of one buffer -- one convolution of the 2N-image stack per layer, forward / backward-data / weight
+    gradient (with the private branch's rank-2 term in its reduction pass), norm + affine per branch
+    (models/resnet_passport.lockstep_pair, passport_ops.StackShare) -- against one pass per branch
+    (DEEPIPR_NO_STACKED_BRANCHES=1): same losses, same post-step parameters and norm statistics to rounding (the stacked
+    convolution splits K differently and sums the branches' weight gradients in another order), fewer launches."""
+    from deepipr_amd import _lib
+    from deepipr_amd.experiments.trainer_private import DualBranch, train_step_v23
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.flat_sgd import FlatSGD
+    from deepipr_amd.models import resnet_passport as rp
+    from oracle.cases import resnet18_config
+    arch, n = case.split('_bs')
+    n = int(n)
+    cfg = resnet18_config() if arch == 'resnet18' else alexnet_config()
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random', 'sl_ratio': 0.1})
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 100, (n,), generator=g).to(DEV)
+    res = {}
+    for mode in ('stacked', 'per_branch'):
+        monkeypatch.setattr(rp, '_STACKED', mode == 'stacked')
+        torch.manual_seed(4)
+        np.random.seed(4)
+        if arch == 'resnet18':
+            from deepipr_amd.models.resnet_passport_private import ResNet18Private
+            net = ResNet18Private(num_classes=100, passport_kwargs=kw).to(DEV)
+        else:
+            from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
+            net = AlexNetPassportPrivate(3, 100, kw).to(DEV)
+        net.train()
+        with torch.no_grad():
+            net(x)
+        dual = DualBranch(net)
+        opt = FlatSGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        _lib.profile_enable(True)
+        outs = tuple(float(v) for v in train_step_v23(dual, opt, x, y))
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        convs = sum(int(prof[k][1]) for k in ('conv_fwd', 'conv_wino_fwd', 'conv_dgrad', 'conv_wino_dgrad', 'conv_wgrad'))
+        sl = [float(m.sign_loss_private.loss) for m in net.modules() if hasattr(m, 'sign_loss_private')]
+        res[mode] = dict(outs=outs, convs=convs, sign=sl, state={k: v.detach().clone() for k, v in net.state_dict().items()})
+    a, b = res['stacked'], res['per_branch']
+    assert a['convs'] < b['convs'], (a['convs'], b['convs'])              # the stack really convolves once per layer
+    assert np.allclose(a['outs'], b['outs'], rtol=1e-5, atol=1e-5), (a['outs'], b['outs'])
+    assert np.allclose(a['sign'], b['sign'], rtol=1e-6, atol=1e-7)
+    worst = (0.0, None)
+    for k, v in b['state'].items():
+        if k.endswith('num_batches_tracked'):
+            assert int(a['state'][k]) == int(v), k
+            continue
+        err = float((a['state'][k] - v).abs().max())
+        worst = max(worst, (err / (float(v.abs().max()) + 1e-12), k))
+        assert err <= 1e-4 * float(v.abs().max()) + 5e-6, (k, err)
+    print('stacked vs per-branch: %d vs %d own convolution launches, worst state difference %.2e of scale (%s)'
+          % (a['convs'], b['convs'], worst[0], worst[1]))
 
 
 @pytest.mark.parametrize('net_kind', ['resnet18_v1', 'resnet18_v2'])
