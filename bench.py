@@ -79,13 +79,27 @@ def _leave():
     """End of a rank.  With RCCL ranks the process leaves WITHOUT tearing the communicator down: a benchmark whose line is
     already printed must not turn into a non-zero exit code because a library thread objects during teardown (the one
     abort seen there in round 4 was RCCL's watchdog, whose poll had fallen inside a stream capture -- the captures are
-    now preceded by distributed.retire_collectives(); profiles/r04_nccl_flake_probe.txt).  Everything else (one process,
-    gloo rehearsals, the dry run) shuts down normally."""
+    now preceded by distributed.retire_collectives(); profiles/r04_nccl_flake_probe.txt).  The ranks meet at a last barrier
+    first -- rank 0 reaches it after it has printed its line, so no peer is gone before the result is out and a late failure
+    of rank 0 is not mistaken for a peer's early exit -- and the process runs its atexit handlers (profilers and tracers
+    flush their output there) before it leaves.  DEEPIPR_BENCH_HARD_EXIT=0 takes the ordinary shutdown instead.
+    Everything else (one process, gloo rehearsals, the dry run) shuts down normally."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() > 1:
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        try:
+            D.barrier()
+        except Exception as e:                               # a peer is gone: say so, leave anyway
+            print('bench.py: final barrier failed: %s' % e, file=sys.stderr, flush=True)
+        if os.environ.get('DEEPIPR_BENCH_HARD_EXIT', '1') != '0':
+            import atexit
+            try:
+                atexit._run_exitfuncs()
+            finally:
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0)
     D.shutdown()
 
 
@@ -381,6 +395,10 @@ def main():
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find-mode, as train_v1.py:8
 
+    own_policy = None
+    if world > 1:
+        from deepipr_amd import passport_ops as _po
+        own_policy = _po.prefer_own_kernels()              # every rank on the same, bit-reproducible kernels
     model = build_model(args, device)
     note('model built')
     if args.no_fuse:
@@ -453,10 +471,14 @@ def main():
     # the yardstick for the line above: the SAME rank running the same pass twice (vendor kernels that accumulate with
     # atomics make even that differ in the low bits; this library's kernels do not)
     repeat = None
+    census_same, census = None, None
     if many:
         first = D.gradient_digest(probe.pop('grads'), device)
+        _lib.profile_enable(True)                          # ... and which of this library's kernel families served it, per rank
         find_pass()
         torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        census_same, census = D.launch_census_agrees({k: v[1] for k, v in _lib.profile_read().items()}, device)
         again = D.gradient_digest(probe.pop('grads'), device)
         rb, rc, rd = D.digests_agree(first, again)
         repeat = {'bitwise': rb, 'weights_1e-5': rc, **rd}
@@ -650,6 +672,10 @@ def main():
         # after the find phase every rank ran the same forward + backward (rank 0's batch, broadcast weights): identical
         # gradients bit for bit / within 1e-5 of scale (None on one GPU)
         'ranks_agree_bitwise': agree, 'ranks_agree_1e-5': agree_tol, 'ranks_agree_detail': agree_detail, 'same_rank_repeat_agrees': repeat,
+        # the same pass counted per kernel family of this library (profile slots): equal tables = every rank routed every
+        # layer to the same kernels; own_conv_policy 'all' (set for N > 1) leaves only the stem forward and the classifier
+        # GEMM to the vendor library
+        'ranks_same_kernel_census': census_same, 'kernel_census_rank0': census, 'own_conv_policy': own_policy,
         'find_phase_exchange_timeouts': find_timeouts, 'find_phase_s': round(find_s, 1),
         'exchange_us_exposed': None if exposed_us is None else round(exposed_us, 1),
         'config': {'workload': ('%s V%s passport (%s_passport.json: %d passport layers), '

@@ -104,19 +104,42 @@ def barrier():
             dist.barrier()
 
 
-def retire_collectives(seconds=0.5):
-    """Call before a hipGraph capture when an RCCL process group is alive: wait until its watchdog thread has retired every
-    collective issued so far.  The watchdog polls the end event of each unretired collective about every 100 ms; a poll
-    that falls INSIDE a stream capture of the main thread comes back as `hipErrorCapturedEvent` ("operation not permitted
-    on an event last recorded in a capturing stream") on ROCm 7.2 / torch 2.10 -- also in capture_error_mode
-    "thread_local" -- and the watchdog answers by terminating the process.  Measured: one run in five of a process that
-    captures within a few hundred ms of its last collective (tools/nccl_flake_probe.sh,
-    profiles/r04_nccl_flake_probe.txt).  Finished collectives leave the list at the next poll, so: drain the device,
-    then give the watchdog a few polls."""
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
-        import time
-        torch.cuda.synchronize()
-        time.sleep(seconds)
+def retire_collectives(seconds=0.0):
+    """Call before a hipGraph capture when an RCCL process group is alive: return only when its watchdog thread has RETIRED
+    every collective issued so far.  The watchdog polls the end event of each unretired collective about every 100 ms; a
+    poll that falls INSIDE a stream capture of the main thread comes back as `hipErrorCapturedEvent` ("operation not
+    permitted on an event last recorded in a capturing stream") on ROCm 7.2 / torch 2.10 -- also in capture_error_mode
+    "thread_local" -- and the watchdog answers by terminating the process (one fresh process in five that captures within a
+    few hundred ms of its last collective: tools/nccl_flake_probe.sh, profiles/r04_nccl_flake_probe.txt).
+    A CONDITION, not a pause (round 4 slept half a second and hoped): drain the device, so that every collective's end
+    event has fired, then block in ProcessGroup._wait_for_pending_works() of every RCCL group -- c10d's own
+    waitForPendingWorks: it returns when the watchdog's work list is EMPTY, and an empty list is nothing to poll.  The
+    calling thread issues no collective between this call and the end of its capture (bench.py, StepRunner: the capture
+    follows immediately), so the list stays empty for as long as it matters.  `seconds` > 0 adds a pause on top (the probe's
+    A/B knob); a torch without the call falls back to half a second of pause, as before."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    groups = [pg for pg in list(dist.distributed_c10d._world.pg_map) if _is_rccl(pg)]
+    if not groups:
+        return
+    import time
+    torch.cuda.synchronize()
+    waited = True
+    for pg in groups:
+        wait = getattr(pg, '_wait_for_pending_works', None)
+        if wait is None:
+            waited = False
+        else:
+            wait()
+    if seconds > 0 or not waited:
+        time.sleep(seconds if waited else max(seconds, 0.5))
+
+
+def _is_rccl(pg):
+    try:
+        return dist.get_backend(pg) == 'nccl'
+    except Exception:                                           # a group this rank is not part of
+        return False
 
 
 def shutdown():
@@ -195,6 +218,22 @@ def digests_agree(a, b):
     nonfinite = int((~torch.isfinite(t_a[:, :2])).sum() + (~torch.isfinite(t_b[:, :2])).sum())
     detail = {'worst_rel_weights': worst_w, 'worst_rel_1d': worst_v, 'nonfinite_sums': nonfinite}
     return bool(int(bits_a) == int(bits_b)), bool(worst_w <= 1e-5 and nonfinite == 0), detail
+
+
+def launch_census_agrees(counts, device):
+    """counts: this rank's {profile slot: launches} of one forward + backward (deepipr_amd._lib.profile_read()).  Do all
+    ranks report the same table, i.e. did they route every layer to the same kernel family of this library (and hence the
+    same set of layers to the vendor library)?  -> (equal on every rank, rank 0's non-zero entries); (None, None) without a
+    process group.  One small all-gather."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return None, None
+    names = sorted(counts)
+    mine = torch.tensor([int(counts[k]) for k in names], dtype=torch.int64,
+                        device='cpu' if dist.get_backend() == 'gloo' else device)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    same = all(bool(torch.equal(every[0], t)) for t in every[1:])
+    return same, {k: int(v) for k, v in zip(names, every[0].tolist()) if v}
 
 
 def gradients_agree(grads, device):

@@ -134,6 +134,9 @@ class StepRunner:
         self.step_fn, self.model, self.optimizer = step_fn, model, optimizer
         self.graph = graph
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.distributed and torch.distributed.get_world_size() > 1:
+            from deepipr_amd import passport_ops
+            passport_ops.prefer_own_kernels()                  # every rank on the same, bit-reproducible kernels
         self._graphed = None
         self._shape = None
         self._probe = None                 # staged data-parallel step: (replays left to watch, state to fall back to)
@@ -155,8 +158,10 @@ class StepRunner:
             if self.distributed and hasattr(self._graphed, 'describe') and hasattr(self.optimizer, 'flat_buf'):
                 # The staged step lets collectives overlap the split-channel single-pass kernels (policy "shared",
                 # staged.py); should their in-launch exchange ever time out next to one, the first replays show it.
-                # Watch them, all ranks together, instead of finding NaN statistics at the end of the epoch.
-                self._probe = [3, {k: v.clone() for k, v in self.model.state_dict().items()}, self.optimizer.flat_buf.clone()]
+                # Watch the FIRST one, all ranks together, instead of finding NaN statistics at the end of the epoch: checked
+                # right after it, a time-out costs nothing but this one batch run twice -- no batch is dropped and no
+                # poisoned output reaches the caller's meters (three watched replays lost two batches).
+                self._probe = [1, {k: v.clone() for k, v in self.model.state_dict().items()}, self.optimizer.flat_buf.clone()]
             return self._watched(self._graphed(data, target), data, target)      # capture does not execute: replay the first batch
         if (tuple(data.shape), tuple(target.shape)) != self._shape:
             return self.step_fn(self.model, self.optimizer, data, target)
@@ -172,15 +177,17 @@ class StepRunner:
         kernels = passport_ops.kernels
         if data.is_cuda:
             torch.cuda.synchronize()
-        ok = torch.tensor([0.0 if kernels.sync_timeouts() else 1.0], device=data.device)
-        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)       # every rank takes the same form
+        # every rank takes the same form; a gloo group reduces host tensors (as distributed.ranks_seen does)
+        on_host = torch.distributed.get_backend() == 'gloo'
+        ok = torch.tensor([0.0 if kernels.sync_timeouts() else 1.0], device='cpu' if on_host else data.device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
         _n, state, flat = self._probe
         self._probe = None
         if float(ok.item()) > 0.5:
             return out
         print('deepipr_amd: an in-launch exchange of the single-pass norm kernels timed out next to a collective on some '
-              'rank; all ranks fall back to the three-launch form for the split-channel layers, restore the state of three '
-              'steps ago and capture the step again', flush=True)
+              'rank; all ranks fall back to the three-launch form for the split-channel layers, restore the state from '
+              'before this step, capture the step again and run this batch through it', flush=True)
         kernels.set_user_sync(False)
         kernels.reset_sync_words()
         if hasattr(self._graphed, 'close'):

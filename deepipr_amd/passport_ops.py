@@ -920,6 +920,25 @@ OWN_CONV = os.environ.get('DEEPIPR_OWN_CONV', 'auto')
 OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0' and OWN_CONV != '0'
 
 
+_OWN_CONV_FROM_ENV = 'DEEPIPR_OWN_CONV' in os.environ
+
+
+def prefer_own_kernels():
+    """Data-parallel runs: every convolution this library has a kernel for takes it, whatever the speed policy says
+    (OWN_CONV 'auto' -> 'all'; an explicit DEEPIPR_OWN_CONV in the environment is left alone).  The ranks of a job must run
+    the SAME kernels -- weak-scaling time is the slowest rank's, and their gradients should agree bit for bit -- and the one
+    thing that differed between ranks in round 4's rehearsal was the vendor library's solver choice for the shapes `auto`
+    leaves to it (rank 1 reads rank 0's find records but takes its own immediate-mode decision where one is missing:
+    5.6e-5 of scale between the ranks' gradients).  This library's kernels leave nothing to choose and are
+    bit-reproducible; what stays with the vendor library afterwards is the 3-channel stem's forward and the classifier GEMM.
+    Costs a few us per step on one GPU (layer4.0's stride-2 forward / backward-data at 2 048 positions).  -> the policy now."""
+    global OWN_CONV, OWN_WGRAD
+    if not _OWN_CONV_FROM_ENV and OWN_CONV == 'auto':
+        OWN_CONV = 'all'
+        OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0'
+    return OWN_CONV
+
+
 def _own_ok(t, w):
     return t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and w.dim() == 4 and w.shape[2] == w.shape[3]
 

@@ -427,13 +427,19 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
  * (OIHW).  With dgamma / dbeta / m (all three or none) that launch also adds the passport branch's term,
  * dW[co][k] += dgamma[co] * m[0][k] + dbeta[co] * m[1][k]  (deepipr_gamma_beta_bwd_acc's arithmetic), so the shared
  * weight's three-way gradient is complete when it is first written.
- * Supported: 3x3, stride 1, pad 1, Ci and Co multiples of 64, maps 4 / 8 / 16 / 32 wide (H a multiple of the row band:
- * 4 / 8 / 4 / 2 rows; N even for 4-wide maps).  Anything else: deepipr_conv_wgrad_workspace_bytes returns 0 and
- * deepipr_conv_wgrad returns DEEPIPR_EUNSUPPORTED without enqueuing anything -- the caller keeps the library's wgrad.
+ * Supported (H, W: the INPUT map; dy is [N][Co][H / stride][W / stride]; Ci, Co multiples of 64 unless said otherwise):
+ *   3x3 pad 1 stride 1   output maps 4 / 8 / 16 / 32 wide, H a multiple of the row band 4 / 8 / 4 / 2, N even on 4-wide maps;
+ *   3x3 pad 1 stride 2   output maps 4 / 8 / 16 wide, output height a multiple of 4 / 4 / 2;
+ *   1x1 pad 0 stride 2   output maps 4 / 8 / 16 wide, output height a multiple of 4 / 8 / 4, N even on 4-wide maps
+ *                        (the projection shortcuts; models/resnet_passport.py:33-36);
+ *   3x3 pad 1 stride 1 with Ci = 3 on 32-wide maps, H a multiple of 4 (the CIFAR stem): NO fused rank-2 term -- with dgamma /
+ *                        dbeta / m the call returns DEEPIPR_EUNSUPPORTED (add it with deepipr_gamma_beta_bwd_acc).
+ * Anything else: deepipr_conv_wgrad_workspace_bytes returns 0 and deepipr_conv_wgrad returns DEEPIPR_EUNSUPPORTED without
+ * enqueuing anything -- the caller keeps the library's wgrad.
  * replaces: the weight half of aten::convolution_backward behind `self.conv(x)`,
  *           models/layers/passportconv2d.py:218 (private twin :215), models/layers/conv2d.py:31 -- MIOpen's
  *           igemm_wrw_gtcx35_nhwc + batched_transpose_* + SubTensorOpWithScalar1d (profiles/r03_steady_state.md).
- * x [N][Ci][H][W]   dy [N][Co][H][W]   dW [Co][Ci][3][3]   m [2][Ci*9] double   all pointers 16-byte aligned
+ * x [N][Ci][H][W]   dy [N][Co][H/stride][W/stride]   dW [Co][Ci][k][k]   m [2][Ci*k*k] double   all pointers 16-byte aligned
  *
  * Arithmetic (ABI v8).  Default: fp32 in, fp32 MFMA, fp32 out, as described above.  Opt-in -- deepipr_conv_set_arith(1),
  * or DEEPIPR_CONV_ARITH=bf16x3 in the environment at load time -- the 3x3 stride-1 instances on maps 8 / 16 / 32 wide run
