@@ -41,6 +41,10 @@ bool dispatch(const FwPlan &p, const float *wgt, const float *in, float *out, in
         case 2: DIPR_WINO(16, 4, 1)
         case 1: DIPR_WINO(8, 4, 2)
         case 0: DIPR_WINO(4, 2, 8)
+        case 7: DIPR_WINO(56, 1, 1)
+        case 6: DIPR_WINO(28, 2, 1)
+        case 5: DIPR_WINO(14, 4, 1)
+        case 4: DIPR_WINO(7, 4, 2)
         default: return false;
     }
 #undef DIPR_WINO

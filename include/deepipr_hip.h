@@ -493,8 +493,10 @@ size_t deepipr_conv_workspace_bytes(int N, int Ci, int Co, int H, int W, int k, 
  * 4x4 input tiles (B^T d B) straight out of the staged NCHW band, sixteen batched 32 x 32 x 2 MFMA GEMMs over channel pairs,
  * the output transform in the epilogue: 16 instead of 36 multiplies per 2x2 outputs and channel, NCHW in and out, fixed
  * summation order (bit-reproducible), exact on small-integer operands; against float64 a few 1e-7 of the output scale (the
- * algorithm the vendor library runs for these layers on the vector ALUs, miopenSp3AsmConv_*_f2x3).  Any N (ragged image
- * groups are masked), Ci a multiple of 8, Co of 32, maps 4 / 8 / 16 / 32 wide, H a multiple of 4 / 8 / 8 / 4.
+ * algorithm the vendor library runs for these layers on the vector ALUs, miopenSp3AsmConv_*_f2x3).  Any N and any H
+ * (ragged image groups, ragged row bands and the half-empty last tiles of odd maps are masked), Ci a multiple of 8 and Co
+ * of 32 (backward-data: the other way round), maps 4 / 8 / 16 / 32 wide (CIFAR geometry) and 7 / 14 / 28 / 56 wide
+ * (ImageNet geometry: 28 of a workgroup's 32 tile columns busy).
  * 0: the direct implicit GEMM above (also what every other shape takes).  DEEPIPR_CONV_ALGO=direct|winograd in the
  * environment at load time sets the default.  Process-wide, read when a call is planned: do not change it between
  * deepipr_conv_supported / _workspace_bytes and the call.  deepipr_conv_algo_of: the algorithm a call of this shape takes. */

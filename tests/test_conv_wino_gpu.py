@@ -42,6 +42,10 @@ SHAPES = [
     (128, 128, 128, 16, 16), (32, 128, 128, 16, 16), (3, 128, 64, 16, 16), (66, 128, 128, 16, 16),
     (128, 256, 256, 8, 8), (32, 256, 256, 8, 8), (3, 256, 128, 8, 8), (66, 256, 256, 8, 8), (5, 96, 32, 16, 8),
     (128, 512, 512, 4, 4), (32, 512, 512, 4, 4), (66, 512, 512, 4, 4), (4, 192, 64, 4, 4), (13, 160, 32, 8, 4), (8, 512, 512, 4, 4),
+    # ImageNet geometry (ResNet18 / ResNet50 at 224 x 224: 56-, 28-, 14- and 7-wide maps; 28 of a workgroup's 32 tile columns
+    # busy, odd maps with half-empty last tiles, rows that start on any 4-byte boundary), ragged bands, odd heights
+    (4, 64, 64, 56, 56), (3, 128, 128, 28, 28), (5, 256, 256, 14, 14), (6, 512, 512, 7, 7), (3, 64, 32, 7, 7), (2, 64, 96, 10, 56),
+    (2, 32, 64, 5, 16), (1, 96, 64, 9, 28), (7, 64, 64, 3, 14), (33, 256, 256, 14, 14), (32, 512, 512, 7, 7),
 ]
 
 
@@ -111,8 +115,8 @@ def test_winograd_agrees_with_the_direct_kernel(K):
 def test_one_hot_operands_are_exact(K):
     """Small-integer one-hot inputs: the transforms only add and halve, so every product and sum is exact -- a wrong tap, a
     halo that is not zero, a tile written to the wrong pixel or a band leaking into its neighbour is an exact mismatch."""
-    for hw in (4, 8, 16, 32):
-        n, c = 9, 64
+    for hw in (4, 8, 16, 32, 7, 14, 28, 56):
+        n, c = (9, 64) if hw <= 32 else (2, 64)
         rs = np.random.RandomState(hw)
         x = torch.zeros(n, c, hw, hw, device=DEV)
         dy = torch.zeros(n, c, hw, hw, device=DEV)
@@ -132,7 +136,7 @@ def test_one_hot_operands_are_exact(K):
 def test_every_tap_and_every_pixel(K):
     """A filter with ONE non-zero tap shifts the image: all nine taps, both directions, on every map width -- the output must
     be the shifted input exactly (zero padded), pixel for pixel."""
-    for hw in (4, 8, 16, 32):
+    for hw in (4, 8, 16, 32, 7, 14, 28, 56):
         n, c = 2, 32
         x = torch.arange(n * c * hw * hw, device=DEV, dtype=torch.float32).reshape(n, c, hw, hw) % 251.0
         dy = torch.arange(n * c * hw * hw, device=DEV, dtype=torch.float32).reshape(n, c, hw, hw) % 127.0

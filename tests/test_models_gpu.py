@@ -179,10 +179,13 @@ WHOLE_NET_CASES = {
     'alexnet_v1': ('alexnet', False, 64, 10, 'bn'),              # config A
     'resnet18_v1_gn': ('resnet18', False, 64, 10, 'gn'),
     'resnet18_v1_in': ('resnet18', False, 64, 10, 'in'),
+    # ImageNet geometry (models/resnet_passport.py:94-98: 7x7 / 2 stem + max-pool, 1000 classes; 56 / 28 / 14 / 7-wide maps:
+    # the Winograd kernels' 28-of-32-lane instances, the vendor library for the stem, the stride-2 and the weight gradients)
+    'resnet18_v1_imagenet': ('resnet18', False, 32, 1000, 'bn', 224),
 }
 
 
-def _whole_net_pair(arch, private, n, ncls, norm):
+def _whole_net_pair(arch, private, n, ncls, norm, hw=32):
     """Product net on the GPU and the oracle's net with the same pattern-filled weights, keys and batch."""
     from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
     from oracle.cases import resnet18_config
@@ -202,7 +205,7 @@ def _whole_net_pair(arch, private, n, ncls, norm):
         from deepipr_amd.models.alexnet_passport_private import AlexNetPassportPrivate
         prod = (AlexNetPassportPrivate if private else AlexNetPassport)(3, ncls, kw).to(DEV)
         ref = torch_ref.AlexNetRef(3, ncls, kw_ref, private=private)
-    x, y = patterns.batch(n, 3, 32, 32, ncls)
+    x, y = patterns.batch(n, 3, hw, hw, ncls)
     prod.train()
     ref.train()
     with torch.no_grad():
@@ -237,8 +240,8 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
     from deepipr_amd.models.layers.conv2d import ConvBlock
     monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
     tol = 1e-4
-    arch, private, n, ncls, norm = WHOLE_NET_CASES[case]
-    prod, ref, x, y = _whole_net_pair(arch, private, n, ncls, norm)
+    arch, private, n, ncls, norm = WHOLE_NET_CASES[case][:5]
+    prod, ref, x, y = _whole_net_pair(arch, private, n, ncls, norm, *WHOLE_NET_CASES[case][5:])
     ref = ref.double().to(DEV)
     xg, yg = x.to(DEV), y.to(DEV)
     x64 = xg.double()

@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--imagenet', action='store_true', help='the 3x3 stride-1 shapes of ResNet18 / ResNet50 at 224 x 224')
     ap.add_argument('--algo', default=None, choices=['direct', 'winograd'], help='3x3 stride-1 algorithm (default: the library default)')
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
@@ -46,7 +47,8 @@ def main():
         K.set_conv_algo(args.algo)
     dev = torch.device('cuda:0')
     out = []
-    for ci, co, hw, k, st in SHAPES:
+    shapes = [(64, 64, 56, 3, 1), (128, 128, 28, 3, 1), (256, 256, 14, 3, 1), (512, 512, 7, 3, 1)] if args.imagenet else SHAPES
+    for ci, co, hw, k, st in shapes:
         n, pad = args.batch, k // 2
         g = torch.Generator(device='cpu').manual_seed(ci + hw + k)
         x = torch.randn(n, ci, hw, hw, generator=g).to(dev)
