@@ -773,7 +773,9 @@ def main():
             'conv_wino_fwd': ('k_conv_wino (forward of the 3x3 stride-1 data convolutions: Winograd F(2x2, 3x3) around '
                               'v_mfma_f32_32x32x2_f32)', 1.0),
             'conv_wino_dgrad': ('k_conv_wino (backward-data of the 3x3 stride-1 data convolutions: Winograd F(2x2, 3x3) around '
-                                'v_mfma_f32_32x32x2_f32)', 1.0)}
+                                'v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv_wino_wgrad': ('k_conv_wino_wgrad (weight gradient of the 3x3 stride-1 data convolutions: Winograd F(3x3, 2x2) '
+                                'around v_mfma_f32_32x32x2_f32; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)', 1.0)}
         rms, rn = prof.get('conv_wgrad_reduce', (0.0, 0))
         mfma, mfma_all = None, {}
         for slot, (what, issued) in MFMA_SLOTS.items():
@@ -800,7 +802,7 @@ def main():
                 rec['note'] += (' (6 bf16 MFMA products per fp32 product) against the dense bf16 peak; the algorithmic rate is '
                                 'also given against the fp32 MFMA peak (%.1f TFLOP/s), which an fp32-MFMA kernel cannot exceed'
                                 % MFMA_F32_PEAK_TFLOPS)
-            if slot.startswith('conv_wgrad'):
+            if slot.startswith('conv_wgrad') or slot == 'conv_wino_wgrad':
                 rec['reduce_us_per_step_all_wgrads'] = round(1000.0 * rms / sampled, 1)
             if slot == 'conv_wgrad' and args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32:
                 # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,

@@ -25,6 +25,11 @@ DIPR_HIDDEN FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k,
 // dispatch's own start / stop events when the caller times it (both or neither).  -> false: no instance for p.cfg.
 DIPR_HIDDEN bool dipr_launch_conv_wino(const FwPlan &p, bool dgrad, const float *wgt, const float *in, float *out, int N, int Cin,
                                        int M, int H, float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b);
+// Winograd F(3x3, 2x2) weight gradient (deepipr_conv_wino_wgrad.inc) on a `width`-wide map (4 / 8 / 16 / 32): 64 co x 32 ci
+// partial tiles in k_conv3x3_wgrad's CIT = 32 layout, chunks of 16 tiles (images per chunk: 4 / 1 / 1 / 1, tile rows 2 / 4 / 2 / 1).
+DIPR_HIDDEN bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *part, int N, int Ci, int Co, int H,
+                                        int tiles_co, int tiles_ci, int chunks, int chunks_per_split, int grid, hipStream_t st,
+                                        hipEvent_t ev_a, hipEvent_t ev_b);
 #ifdef DEEPIPR_TRACE
 DIPR_HIDDEN bool dipr_wino_set_trace(unsigned long long *device_buffer);
 #endif

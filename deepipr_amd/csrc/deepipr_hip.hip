@@ -4068,6 +4068,17 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
 // data convolution: weight gradient on the fp32 matrix cores (kernels and planner: deepipr_conv.inc)
 // =============================================================================================
 namespace {
+// Algorithm of the 3x3 stride-1 convolutions, all three directions: 1 = Winograd (F(2x2, 3x3) forward / backward-data,
+// deepipr_conv_wino.inc; F(3x3, 2x2) weight gradient, deepipr_conv_wino_wgrad.inc; default), 0 = the direct implicit GEMMs.  DEEPIPR_CONV_ALGO=direct|winograd at load time, deepipr_conv_set_algo afterwards.
+int g_conv_algo = -1;
+int conv_algo() {
+    if (g_conv_algo < 0) {
+        const char *e = getenv("DEEPIPR_CONV_ALGO");
+        g_conv_algo = (e && !strcmp(e, "direct")) ? 0 : 1;
+    }
+    return g_conv_algo;
+}
+
 #include "deepipr_conv.inc"
 #include "deepipr_conv_fwd.inc"
 
@@ -4130,7 +4141,15 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
                        p.splits);
         return check_launch("conv_wgrad");
     }
-    {
+    if (p.cfg >= 5000) {                                               // Winograd F(3x3, 2x2)
+        ProfScope prof(DEEPIPR_K_CONV_WINO_WGRAD, st);
+        prof.bytes = 2.0 * Co * Ci * 16.0 * static_cast<double>(N) * (H / 2) * (W / 2);          // EXECUTED FLOPs (direct: x 2.25)
+        const bool timed = prof.a && !prof.used;
+        if (!dipr_launch_wgrad_wino(p.cfg - 5000, x, dy, part, N, Ci, Co, H, p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split,
+                                    grid, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))
+            return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no instance");
+        if (timed) prof.used = true;
+    } else {
         ProfScope prof(p.cfg >= 4000 ? DEEPIPR_K_CONV_WGRAD_B3 : DEEPIPR_K_CONV_WGRAD, st);
         prof.bytes = 2.0 * Co * Ci * p.taps * static_cast<double>(N) * (H / stride) * (W / stride);     // FLOPs, not bytes: this kernel's roofline is the MFMA peak
 #define DEEPIPR_WGRAD_1X1(...)                                                                                        \
@@ -4196,17 +4215,6 @@ void launch_gemm(ProfScope &prof, const FwPlan &p, const float *wgt, const float
                            ws, p.grid, p.cps, p.slab);
     else DEEPIPR_LAUNCH(prof, (k_conv_gemm<C, DGRAD>), dim3(p.grid), dim3(256), st, wgt, in, out, Cin, M, H, p.bands,
                         static_cast<float *>(nullptr), p.grid, Cin, p.slab);
-}
-
-// Algorithm of the 3x3 stride-1 forward / backward-data: 1 = Winograd F(2x2, 3x3) (deepipr_conv_wino.inc; default),
-// 0 = the direct implicit GEMM.  DEEPIPR_CONV_ALGO=direct|winograd at load time, deepipr_conv_set_algo afterwards.
-int g_conv_algo = -1;
-int conv_algo() {
-    if (g_conv_algo < 0) {
-        const char *e = getenv("DEEPIPR_CONV_ALGO");
-        g_conv_algo = (e && !strcmp(e, "direct")) ? 0 : 1;
-    }
-    return g_conv_algo;
 }
 
 // the plan a 3x3 / 1x1 forward-shaped GEMM call takes: Winograd where it applies and is switched on, else the direct form

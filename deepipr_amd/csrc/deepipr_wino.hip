@@ -14,6 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 inline int device_cu_count() { return dipr_device_cu_count(); }
 #include "deepipr_conv_wino.inc"
+#include "deepipr_conv_wino_wgrad.inc"
 
 template <class C, bool DGRAD>
 void launch(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, float *ws, hipStream_t st,
@@ -50,6 +51,26 @@ bool dispatch(const FwPlan &p, const float *wgt, const float *in, float *out, in
 #undef DIPR_WINO
 }
 }  // namespace
+
+bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *part, int N, int Ci, int Co, int H, int tiles_co,
+                            int tiles_ci, int chunks, int chunks_per_split, int grid, hipStream_t st, hipEvent_t a, hipEvent_t b) {
+#define DIPR_WW(WW, TBR, NIB)                                                                                          \
+    do {                                                                                                              \
+        if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(256), 0, st, a, b, 0, x, dy, part, N, \
+                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split);                        \
+        else hipLaunchKernelGGL((k_conv_wino_wgrad<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(256), 0, st, x, dy, part, N, Ci, Co, H,   \
+                                tiles_co, tiles_ci, chunks, chunks_per_split);                                        \
+        return true;                                                                                                  \
+    } while (0)
+    switch (width) {
+        case 32: DIPR_WW(32, 1, 1);
+        case 16: DIPR_WW(16, 2, 1);
+        case 8: DIPR_WW(8, 4, 1);
+        case 4: DIPR_WW(4, 2, 4);
+        default: return false;
+    }
+#undef DIPR_WW
+}
 
 FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride, int pad) {
     return plan_conv_wino(N, C, M, H, W, k, stride, pad);

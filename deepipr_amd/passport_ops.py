@@ -677,6 +677,7 @@ class HipKernels:
         self._conv_ok.clear()
         self._conv_ws.clear()
         self._conv_wino.clear()
+        self._wgrad_ws.clear()
         return before
 
     def conv_algo(self):
@@ -1036,7 +1037,7 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     if need_dw and _own_wgrad(x_in, w, stride, pad):
         dconv = dconv.contiguous()
         dx = _conv_dgrad(dconv, x_in, w, stride, pad) if need_dx else None
-        if w.shape[1] % 64 == 0:
+        if w.shape[1] % 32 == 0:                       # (every instance but the 3-channel stem's adds the rank-2 term in its reduction)
             return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
         # the 3-channel stem instance has no fused rank-2 term: the separate accumulate pass
         return dx, kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad)), False
@@ -1168,7 +1169,7 @@ class _Conv2dOwn(torch.autograd.Function):
         if ctx.share is not None:
             ctx.share.rank2 = None
         if need_dw and _own_wgrad(x, w, stride, pad):
-            if r2 is not None and w.shape[1] % 64 == 0:
+            if r2 is not None and w.shape[1] % 32 == 0:
                 dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad, *r2)
                 r2 = None
             else:

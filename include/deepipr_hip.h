@@ -87,7 +87,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_SPLIT_SUM 26     /* sum of the split-K output slabs of deepipr_conv_fwd_ws / _dgrad_ws (bytes) */
 #define DEEPIPR_K_CONV_WINO_FWD 27      /* Winograd F(2x2, 3x3) forward: EXECUTED FLOPs (the direct sum's / 2.25) */
 #define DEEPIPR_K_CONV_WINO_DGRAD 28
-#define DEEPIPR_PROFILE_KERNELS 29
+#define DEEPIPR_K_CONV_WINO_WGRAD 29     /* Winograd F(3x3, 2x2) weight gradient: EXECUTED FLOPs */
+#define DEEPIPR_PROFILE_KERNELS 30
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */

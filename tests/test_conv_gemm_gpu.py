@@ -162,7 +162,7 @@ def test_model_level_own_convolutions_equal_the_library_path(K, monkeypatch):
         res[mode] = (y.detach(), x.grad, [p.grad for p in blk.parameters()],
                      (int(prof['conv_fwd'][1]) + int(prof['conv_wino_fwd'][1]),          # direct + Winograd instances
                       int(prof['conv_dgrad'][1]) + int(prof['conv_wino_dgrad'][1]),
-                      int(prof['conv_wgrad'][1]) + int(prof['conv_wgrad_b3'][1])))     # fp32-MFMA + bf16x3 instances
+                      int(prof['conv_wgrad'][1]) + int(prof['conv_wgrad_b3'][1]) + int(prof['conv_wino_wgrad'][1])))     # fp32-MFMA direct + bf16x3 + Winograd instances
     # auto: the stride-1 3x3 takes the Winograd kernel at any size (round 5; the direct kernel needed >= 32 768 positions)
     assert res['all'][3] == (3, 3, 3) and res['auto'][3] == (3, 3, 3) and res['0'][3] == (0, 0, 0)
     K.set_conv_algo('direct')

@@ -495,7 +495,7 @@ def test_stacked_branches_equal_one_pass_per_branch(K, case, monkeypatch):
         torch.cuda.synchronize()
         _lib.profile_enable(False)
         prof = _lib.profile_read()
-        convs = sum(int(prof[k][1]) for k in ('conv_fwd', 'conv_wino_fwd', 'conv_dgrad', 'conv_wino_dgrad', 'conv_wgrad'))
+        convs = sum(int(prof[k][1]) for k in ('conv_fwd', 'conv_wino_fwd', 'conv_dgrad', 'conv_wino_dgrad', 'conv_wgrad', 'conv_wino_wgrad'))
         sl = [float(m.sign_loss_private.loss) for m in net.modules() if hasattr(m, 'sign_loss_private')]
         res[mode] = dict(outs=outs, convs=convs, sign=sl, state={k: v.detach().clone() for k, v in net.state_dict().items()})
     a, b = res['stacked'], res['per_branch']

@@ -68,20 +68,24 @@ def main():
         again = mine()
         bit = bool(torch.equal(got, again))
         t_mine, t_lib = timeit(mine, args.reps), timeit(lib, args.reps)
-        # the same call on the fp32 MFMA (3x3 stride-1 shapes on 8 / 16 / 32-wide maps default to bf16x3)
+        # the same call on the DIRECT fp32-MFMA kernel (the default is Winograd F(3x3, 2x2) for the 3x3 stride-1 shapes, or
+        # bf16x3 when DEEPIPR_CONV_ARITH selects it)
         before = K.set_conv_arith('fp32')
+        algo = K.set_conv_algo('direct')
         got32 = mine()
         torch.cuda.synchronize()
         err32 = float((got32.double() - ref).abs().max()) / scale
         rms = lambda a: float(((a.double() - ref) ** 2).mean().sqrt()) / scale
         t_32 = timeit(mine, args.reps)
         K.set_conv_arith(before)
+        K.set_conv_algo(algo)
         split = not torch.equal(got32, got)
         flops = 2.0 * co * ci * k * k * n * (hw // st) ** 2
         rec = {'Ci': ci, 'Co': co, 'HW': hw, 'k': k, 'stride': st, 'N': n, 'us': round(t_mine, 1), 'us_library': round(t_lib, 1),
                'TFLOPs': round(flops / t_mine / 1e6, 1), 'TFLOPs_library': round(flops / t_lib / 1e6, 1),
                'err_over_scale': err, 'err_library': err_lib, 'bit_reproducible': bit,
-               'arith': K.conv_arith() if split else 'fp32', 'us_fp32_mfma': round(t_32, 1), 'err_fp32_mfma': err32,
+               'arith': K.conv_arith() if split else 'fp32', 'algo': K.conv_algo() if split else 'direct',
+               'us_fp32_mfma': round(t_32, 1), 'err_fp32_mfma': err32,
                'rms_err': rms(got), 'rms_err_fp32_mfma': rms(got32), 'rms_err_library': rms(lib())}
         print(json.dumps(rec), flush=True)
         out.append(rec)
