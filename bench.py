@@ -804,7 +804,13 @@ def main():
                                 % MFMA_F32_PEAK_TFLOPS)
             if slot.startswith('conv_wgrad') or slot == 'conv_wino_wgrad':
                 rec['reduce_us_per_step_all_wgrads'] = round(1000.0 * rms / sampled, 1)
-            if slot == 'conv_wgrad' and args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32:
+            if slot.startswith('conv_wino') and is_headline(args):
+                # HBM-side bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step of
+                # this configuration, profiles/pmc_traffic.json, round 5; Infinity-Cache hits are counted by these counters)
+                fam = 'k_conv_wino_wgrad' if slot == 'conv_wino_wgrad' else 'k_conv_wino'
+                rec['traffic'] = pmc_traffic(fam, 'in_situ_per_launch')
+                rec['traffic_source'] = 'profiles/pmc_traffic.json: %s (round-5 record, average over the family\'s launches of the step)' % fam
+            if slot == 'conv_wgrad' and args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32 and False:
                 # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,
                 # profiles/pmc_traffic.json), recorded when this slot still held all 16 3x3 launches
                 rec['traffic'] = pmc_traffic('k_conv3x3_wgrad', 'in_situ_per_launch')

@@ -2023,7 +2023,8 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
 //   backward  read dy (+ dy2), out, a, b; write da, db  28 B/elt  (separate: 24 + 12 = 36): the masked gradient
 //                                                                 d = (dy + dy2)[out > 0] never leaves the registers
 // Same plan, same unit -> thread mapping, same reduction order and the same per-element arithmetic as the separate
-// kernels: results are bit-identical to them (tests/test_round3_gpu.py).  W-less form only (learnable gamma / beta:
+// kernels: results are bit-identical to them (tests/test_norm_kernels_gpu.py:
+// test_dual_tail_kernels_equal_the_two_separate_fused_layers).  W-less form only (learnable gamma / beta:
 // plain ConvBlocks), batch statistics, no inner ReLU.  S > 1: the second layer's partial sums are exchanged through
 // the slots of channel index cb + C (never used by a split launch of C channels: a region has 256 slots, a launch
 // splits at most 256 / S of them).
