@@ -589,8 +589,8 @@ def test_model_cases_match_reference_goldens(K, name, fuse_norm, golden_dir):
     loose = ('grad/', 'post/', 'stat/', 'logits_eval/', 'train/acc')      # checked below with their own bars
     compare_case(got, gold, rtol=1e-4, atol=1e-4, skip_prefixes=loose + ('ctor_b/',))
     # Bars per key family = 10 x the worst deviation measured over all 17 cases, fused norm on and off
-    # (tools/golden_margins.py, gpurun_out/golden_margins.json -> profiles/r04_golden_margins.json: grad 7.5e-4 of scale,
-    # logits_eval 3.2e-5, post 4.1e-6, stat 1.1e-7).  Round 3 held all four at rtol 5e-3 / atol 1e-3.  The gradient digests
+    # (tools/golden_margins.py -> profiles/r05_golden_margins.json with the Winograd kernels: grad 1.1e-3 of scale,
+    # logits_eval 4.8e-5, post 4.1e-6, stat 8e-8; round 4: 7.5e-4 / 3.2e-5 / 4.1e-6 / 1.1e-7).  Round 3 held all four at rtol 5e-3 / atol 1e-3.  The gradient digests
     # keep that bar: golden batches are 2-8 images, so every norm layer's backward divides by a batch variance of a
     # handful of samples and one flipped ReLU mask moves a whole digest; the tight whole-net gradient bars (1e-4 of
     # scale, kinks gated) are test_whole_net_backward_within_1e4_with_relu_kinks_gated's, at the real batch sizes.
