@@ -132,8 +132,9 @@ def test_conv_wgrad_planner_and_argument_checks_without_a_gpu():
     assert ws(128, 64, 128, 32, 32, 3, 3, 2, 1) > 0 and ws(32, 256, 512, 8, 8, 3, 3, 2, 1) > 0           # stride 2
     assert ws(128, 64, 128, 32, 32, 1, 1, 2, 0) > 0 and ws(128, 64, 128, 32, 32, 1, 1, 2, 1) == 0        # 1x1 stride 2 pad 0
     assert ws(128, 3, 64, 32, 32, 3, 3, 1, 1) > 0                                                         # the stem
+    assert ws(3, 64, 64, 4, 4, 3, 3, 1, 1) > 0 and ws(66, 32, 64, 4, 4, 3, 3, 1, 1) > 0                   # Winograd: ragged image groups, Ci of 32
     for bad in [(128, 3, 64, 16, 16, 3, 3, 1, 1), (128, 4, 64, 32, 32, 3, 3, 1, 1), (128, 64, 64, 64, 64, 3, 3, 2, 1), (128, 64, 64, 32, 32, 3, 3, 3, 1), (128, 64, 64, 32, 32, 1, 1, 1, 0),
-                (128, 64, 64, 14, 14, 3, 3, 1, 1), (128, 64, 80, 8, 8, 3, 3, 1, 1), (3, 64, 64, 4, 4, 3, 3, 1, 1),
+                (128, 64, 64, 14, 14, 3, 3, 1, 1), (128, 64, 80, 8, 8, 3, 3, 1, 1), (3, 64, 48, 4, 4, 3, 3, 1, 1),
                 (0, 64, 64, 8, 8, 3, 3, 1, 1)]:
         assert ws(*bad) == 0, bad
     assert ws(128, 64, 64, 32, 32, 3, 3, 1, 1) % (64 * 64 * 9 * 4) == 0          # whole partial tiles
