@@ -127,3 +127,78 @@ class GraphedTrainStep:
                 p.grad = g
             self.optimizer.step()
         return self.outputs
+
+
+class GraphedEval:
+    """One batch of the test loops (trainer.py:186-204, trainer_private.py:220-241) -- eval-mode forward, summed cross
+    entropy, top-1 class, number of hits -- captured as one hipGraph per batch shape and replayed.
+
+    Why: the eager forward is host-bound (≈ 60 fused nodes through ctypes + Python autograd bookkeeping: 2-3 ms of host time
+    for ≈ 1 ms of kernels at batch 128), and the test set runs through it every epoch.  `forward(data)` is the model call
+    (`lambda d: model(d, ind=1)` for the private branch).  A graph is keyed on the batch shape (the ragged last batch gets
+    its own; at most `max_graphs`, then eager) and stays valid while the things whose ADDRESSES it froze stay put: the
+    parameters / buffers (updated in place by training) and every passport layer's pooled key means (passport_ops.PooledKeys:
+    a key that was replaced or stepped on yields a new tensor -- seen here before every replay, the shape is captured again).
+    Returns (top-1 class [N, 1], summed loss, hits): the graph's own output tensors, overwritten by the next call."""
+
+    def __init__(self, model, forward=None, max_graphs=4):
+        self.model = model
+        self.forward = forward if forward is not None else model
+        self.max_graphs = max_graphs
+        self._graphs = {}
+        self.captures = 0
+        self.stream = None
+
+    def _signature(self):
+        from deepipr_amd.models.layers._passport_base import PassportLayerBase
+        sig = []
+        for m in self.model.modules():
+            if isinstance(m, PassportLayerBase) and m.get_bias_key() is not None and m.get_scale_key() is not None:
+                sig.append(id(m._pooled_means()[2]))
+        sig.extend(t.data_ptr() for t in self.model.parameters())
+        sig.extend(t.data_ptr() for t in self.model.buffers())
+        return tuple(sig)
+
+    @staticmethod
+    def batch(forward, data, target):
+        import torch.nn.functional as F
+        pred = forward(data)
+        loss = F.cross_entropy(pred, target, reduction='sum')
+        top = pred.max(1, keepdim=True)[1]
+        return top, loss, top.eq(target.view_as(top)).sum()
+
+    def _capture(self, data, target):
+        from deepipr_amd import passport_ops
+        from deepipr_amd.distributed import retire_collectives
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        static_data, static_target = data.clone(), target.clone()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):               # library algorithm search, scratch arenas: outside the capture
+            self.batch(self.forward, static_data, static_target)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        passport_ops.kernels.prepare_stream(static_data.device, self.stream)
+        graph = torch.cuda.CUDAGraph()
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        retire_collectives()
+        with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local' if distributed else 'global'):
+            out = self.batch(self.forward, static_data, static_target)
+        self.captures += 1
+        return [graph, static_data, static_target, out, self._signature()]
+
+    def __call__(self, data, target):
+        if not data.is_cuda or self.model.training or torch.is_grad_enabled():
+            return self.batch(self.forward, data, target)
+        key = (tuple(data.shape), tuple(target.shape), data.dtype)
+        entry = self._graphs.get(key)
+        if entry is not None and entry[4] != self._signature():
+            entry = None                                    # a key or a parameter moved: the frozen addresses are stale
+        if entry is None:
+            if key not in self._graphs and len(self._graphs) >= self.max_graphs:
+                return self.batch(self.forward, data, target)
+            entry = self._graphs[key] = self._capture(data, target)
+        graph, static_data, static_target, out, _sig = entry
+        static_data.copy_(data, non_blocking=True)
+        static_target.copy_(target, non_blocking=True)
+        graph.replay()
+        return out

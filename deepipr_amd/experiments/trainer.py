@@ -94,10 +94,23 @@ train_step_v1.forward_loss = forward_loss_v1
 
 
 class Tester(object):
-    def __init__(self, model, device, verbose=True):
+    """graph=True: every batch is one hipGraph replay (experiments/graph_step.GraphedEval, one graph per batch shape) instead
+    of an eager, host-bound forward; same numbers (the same kernels run)."""
+
+    def __init__(self, model, device, verbose=True, graph=False):
         self.model = model
         self.device = device
         self.verbose = verbose
+        self.graph = graph and torch.device(device).type == 'cuda'
+        self._batch = None
+
+    def _run(self, data, target):
+        from deepipr_amd.experiments.graph_step import GraphedEval
+        if not self.graph:
+            return GraphedEval.batch(self.model, data, target)
+        if self._batch is None:
+            self._batch = GraphedEval(self.model)
+        return self._batch(data, target)
 
     def test(self, dataloader, msg='Testing Result', compare=[]):
         self.model.eval()
@@ -109,11 +122,10 @@ class Tester(object):
             for load in dataloader:
                 data = load[0].to(self.device, non_blocking=True)
                 target = load[1].to(self.device, non_blocking=True)
-                pred = self.model(data)
-                loss_sum += F.cross_entropy(pred, target, reduction='sum')
-                top = pred.max(1, keepdim=True)[1]
-                compare.append((top, target))
-                correct += top.eq(target.view_as(top)).sum()
+                top, loss, hits = self._run(data, target)
+                loss_sum += loss
+                compare.append((top.clone() if self.graph else top, target))
+                correct += hits
                 count += data.size(0)
         loss = loss_sum.item() / count
         acc = 100 * correct.item() / count
@@ -207,6 +219,7 @@ class Trainer(object):
         self.device = device
         self.log_interval = log_interval
         self.step = StepRunner(train_step_v1, model, optimizer, graph)
+        self.tester = Tester(model, device, verbose=False, graph=graph)
 
     def train(self, e, dataloader, wm_dataloader=None):
         self.model.train()
@@ -238,7 +251,7 @@ class Trainer(object):
         return {'loss': l, 'sign_loss': s, 'sign_acc': sa, 'acc': a, 'time': time.time() - start}
 
     def test(self, dataloader, msg='Testing Result'):
-        out = Tester(self.model, self.device, verbose=False).test(dataloader, msg, compare=[])
+        out = self.tester.test(dataloader, msg, compare=[])
         print(f'{msg}: Loss: {out["loss"]:6.4f} Acc: {out["acc"]:6.2f} ({out["time"]:.2f}s)')
         print()
         return out

@@ -91,10 +91,22 @@ train_step_v23.forward_loss = forward_loss_v23
 
 
 class TesterPrivate(object):
-    def __init__(self, model, device, verbose=True):
+    """graph=True: every test batch is one hipGraph replay per (branch, batch shape) -- experiments/graph_step.GraphedEval."""
+
+    def __init__(self, model, device, verbose=True, graph=False):
         self.model = model
         self.device = device
         self.verbose = verbose
+        self.graph = graph and torch.device(device).type == 'cuda'
+        self._batch = {}
+
+    def _run(self, model, ind, data, target):
+        from deepipr_amd.experiments.graph_step import GraphedEval
+        if not self.graph:
+            return GraphedEval.batch(lambda d: model(d, ind=ind), data, target)
+        if ind not in self._batch:
+            self._batch[ind] = GraphedEval(model, forward=lambda d: model(d, ind=ind))
+        return self._batch[ind](data, target)
 
     def test_signature(self):
         """sign(gamma) == b per passport layer (trainer_private.py:37-71): 'private_<name>' for
@@ -132,10 +144,9 @@ class TesterPrivate(object):
             for load in dataloader:
                 data = load[0].to(self.device, non_blocking=True)
                 target = load[1].to(self.device, non_blocking=True)
-                pred = model(data, ind=ind)
-                loss_sum += F.cross_entropy(pred, target, reduction='sum')
-                top = pred.max(1, keepdim=True)[1]
-                correct += top.eq(target.view_as(top)).sum()
+                _top, loss, hits = self._run(model, ind, data, target)
+                loss_sum += loss
+                correct += hits
                 count += data.size(0)
         loss = loss_sum.item() / count
         acc = 100 * correct.item() / count
@@ -155,6 +166,7 @@ class TrainerPrivate(object):
         self.device = device
         self.log_interval = log_interval
         self.tester = TesterPrivate(model, device)
+        self.quiet_tester = TesterPrivate(model, device, verbose=False, graph=graph)
 
     def train(self, e, dataloader, wm_dataloader=None):
         self.dual.train()
@@ -188,7 +200,7 @@ class TrainerPrivate(object):
 
     def test(self, dataloader, msg='Testing Result'):
         out = {}
-        quiet = TesterPrivate(self.model, self.device, verbose=False)
+        quiet = self.quiet_tester
         for i, key in enumerate(('public', 'private')):
             r = quiet.test(dataloader, msg, ind=i)
             print(f'{msg} {key}: Loss: {r["loss"]:6.4f} Acc: {r["acc"]:6.2f} ({r["time"]:.2f}s)')

@@ -200,3 +200,55 @@ def test_external_event_of_a_captured_graph_orders_a_side_stream(K):
         ev.synchronize()
         assert bool((big[:: 1 << 12] == float(i)).all()), i
     torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- the test loops as graph replays
+@pytest.mark.miopen_pinned
+@pytest.mark.parametrize('private', [False, True])
+def test_graphed_test_loop_equals_the_eager_one(K, private):
+    """Tester / TesterPrivate with graph=True (GraphedEval: one hipGraph per batch shape, the ragged last batch included)
+    return what the eager loop returns -- the same kernels run -- and keep doing so after the weights moved in place (a
+    training step), after running statistics moved, and after a passport key was replaced (frozen address: captured again)."""
+    from deepipr_amd.experiments.trainer import Tester
+    from deepipr_amd.experiments.trainer_private import TesterPrivate
+    from tests.test_parity_gpu import _fullsize_pair
+    prod, _ref, x, y = _fullsize_pair(private, 37, 10)
+    x, y = x.to(DEV), y.to(DEV)
+    loader = [(x[:16], y[:16]), (x[16:32], y[16:32]), (x[32:], y[32:])]               # 16, 16 and a ragged 5
+    with pinned_miopen():
+        if private:
+            eager, graphed = TesterPrivate(prod, DEV, verbose=False), TesterPrivate(prod, DEV, verbose=False, graph=True)
+            run = lambda t: [t.test(loader, ind=i) for i in (0, 1)]
+        else:
+            eager, graphed = Tester(prod, DEV, verbose=False), Tester(prod, DEV, verbose=False, graph=True)
+
+            def run(t):
+                cmp = []
+                out = t.test(loader, compare=cmp)
+                return [out, [host(a).tolist() for a, _b in cmp]]
+
+        def same():
+            a, b = run(eager), run(graphed)
+            for ra, rb in zip(a, b):
+                if isinstance(ra, dict):
+                    assert ra['loss'] == rb['loss'] and ra['acc'] == rb['acc'], (ra, rb)
+                else:
+                    assert ra == rb
+        same()
+        counters = [g for g in ([graphed._batch] if not private else graphed._batch.values())]
+        assert all(g.captures == 2 for g in counters)                                   # two shapes, one graph each
+        same()
+        assert all(g.captures == 2 for g in counters)                                   # replays only
+        with torch.no_grad():                                                           # weights and statistics move in place
+            for p in prod.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+            for name, b in prod.named_buffers():
+                if name.endswith('running_mean'):
+                    b.add_(0.05)
+        same()
+        assert all(g.captures == 2 for g in counters)
+        layer = next(m for m in prod.modules() if hasattr(m, 'set_key') and m.get_bias_key() is not None)
+        key = layer.get_bias_key()
+        layer.set_key(torch.randn_like(key), torch.randn_like(key))                    # a new key: new pooled means
+        same()
+        assert all(g.captures == 4 for g in counters)
