@@ -97,6 +97,11 @@ SIGNATURES = {
     'deepipr_conv_workspace_bytes': (_sz, [_int] * 9),
     'deepipr_conv_fwd_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
     'deepipr_conv_dgrad_ws': (_int, [_f32p, _f32p, _f32p] + [_int] * 8 + [_vp, _sz, _vp]),
+    'deepipr_conv_wino_image_bytes': (_sz, [_int, _int]),
+    'deepipr_conv_wino_max_layers': (_int, []),
+    'deepipr_conv_wino_transform_multi': (_int, [_vp, _int, _vp]),
+    'deepipr_conv_fwd_pre': (_int, [_f32p, _f32p, _f32p] + [_int] * 5 + [_vp, _sz, _vp]),
+    'deepipr_conv_dgrad_pre': (_int, [_f32p, _f32p, _f32p] + [_int] * 5 + [_vp, _sz, _vp]),
     'deepipr_conv_set_algo': (_int, [_int]),
     'deepipr_conv_get_algo': (_int, []),
     'deepipr_conv_algo_of': (_int, [_int] * 9),
@@ -111,7 +116,7 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_debug_wino_trace': (_int, [_vp]),
 }
-ABI_VERSION = 9
+ABI_VERSION = 10
 SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
@@ -125,6 +130,13 @@ class GemvLayer(_c.Structure):          # DeepiprGemvLayer
 
 class Rank2Layer(_c.Structure):         # DeepiprRank2Layer
     _fields_ = [('dgamma', _vp), ('dbeta', _vp), ('m', _vp), ('dW', _vp), ('Co', _int), ('K', _int)]
+
+
+WINO_MAX_LAYERS = 24                    # DEEPIPR_WINO_MAX_LAYERS
+
+
+class WinoLayer(_c.Structure):          # DeepiprWinoLayer
+    _fields_ = [('W', _vp), ('Uf', _vp), ('Ud', _vp), ('Co', _int), ('Ci', _int)]
 
 
 class HipLibraryMissing(RuntimeError):

@@ -25,6 +25,19 @@ DIPR_HIDDEN FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k,
 // dispatch's own start / stop events when the caller times it (both or neither).  -> false: no instance for p.cfg.
 DIPR_HIDDEN bool dipr_launch_conv_wino(const FwPlan &p, bool dgrad, const float *wgt, const float *in, float *out, int N, int Cin,
                                        int M, int H, float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b);
+// The pre-transformed form (deepipr_conv_wino.inc): `image` = U = G g G^T of this direction's weights as k_wino_weights lays it out
+// (dipr_wino_image_floats(Co, Ci) floats per direction; 0: no such form, Co and Ci must be multiples of 32).  M, Cin: the GEMM's
+// output / input channels (backward-data: M = Ci, Cin = Co, image = Ud).
+DIPR_HIDDEN bool dipr_launch_conv_wino_pre(const FwPlan &p, const float *image, const float *in, float *out, int N, int Cin, int M,
+                                           int H, float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b);
+DIPR_HIDDEN size_t dipr_wino_image_floats(int Co, int Ci);
+DIPR_HIDDEN int dipr_wino_max_layers();
+struct DiprWinoLayer {
+    const float *W;      // [Co][Ci][3][3]
+    float *Uf, *Ud;      // forward / backward-data image (either may be null)
+    int Co, Ci;
+};
+DIPR_HIDDEN bool dipr_launch_wino_weights(const DiprWinoLayer *layers, int n, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b);
 // Winograd F(3x3, 2x2) weight gradient (deepipr_conv_wino_wgrad.inc) on a `width`-wide map (4 / 8 / 16 / 32): 64 co x 32 ci
 // partial tiles in k_conv3x3_wgrad's CIT = 32 layout, chunks of 16 tiles (images per chunk: 4 / 1 / 1 / 1, tile rows 2 / 4 / 2 / 1).
 DIPR_HIDDEN bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *part, int N, int Ci, int Co, int H,

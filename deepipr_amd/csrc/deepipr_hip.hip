@@ -4203,6 +4203,7 @@ case 4032: launch_wgrad_b3<WbCfg<32, 2, 1>>(prof, p, x, dy, part, Ci, Co, H, st)
     return check_launch("conv_wgrad");
 }
 
+
 }  // extern "C"
 
 // =============================================================================================
@@ -4229,7 +4230,7 @@ FwPlan plan_conv_any(int N, int C, int M, int H, int W, int k, int stride, int p
 
 template <bool DGRAD>
 int conv_wino(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, int W,
-              hipStream_t st, const char *what, void *workspace, size_t workspace_bytes) {
+              hipStream_t st, const char *what, void *workspace, size_t workspace_bytes, bool pre = false) {
     if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))
         return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
     // split K needs its slabs: without a workspace one workgroup walks all of K
@@ -4238,8 +4239,9 @@ int conv_wino(const FwPlan &p, const float *wgt, const float *in, float *out, in
         ProfScope prof(DGRAD ? DEEPIPR_K_CONV_WINO_DGRAD : DEEPIPR_K_CONV_WINO_FWD, st);
         prof.bytes = 2.0 * M * Cin * 16.0 * static_cast<double>(N) * (H / 2) * (W / 2);          // EXECUTED FLOPs (direct: x 2.25)
         const bool timed = prof.a && !prof.used;
-        if (!dipr_launch_conv_wino(p, DGRAD, wgt, in, out, N, Cin, M, H, ws, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))
-            return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
+        const bool ok = pre ? dipr_launch_conv_wino_pre(p, wgt, in, out, N, Cin, M, H, ws, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr)
+                            : dipr_launch_conv_wino(p, DGRAD, wgt, in, out, N, Cin, M, H, ws, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr);
+        if (!ok) return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
         if (timed) prof.used = true;
     }
     if (ws) {
@@ -4389,6 +4391,54 @@ int deepipr_conv_dgrad_ws(const float *dy, const float *w, float *dx, int N, int
 int deepipr_conv_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
                        int pad, void *stream) {
     return deepipr_conv_dgrad_ws(dy, w, dx, N, Ci, Co, H, W, k, stride, pad, nullptr, 0, stream);
+}
+
+size_t deepipr_conv_wino_image_bytes(int Co, int Ci) { return dipr_wino_image_floats(Co, Ci) * sizeof(float); }
+
+int deepipr_conv_wino_max_layers(void) { return dipr_wino_max_layers(); }
+
+int deepipr_conv_wino_transform_multi(const DeepiprWinoLayer *layers, int n, void *stream) {
+    if (!layers || n <= 0 || n > dipr_wino_max_layers())
+        return fail(DEEPIPR_EINVAL, "conv_wino_transform_multi: 1..%d layers per call", dipr_wino_max_layers());
+    DiprWinoLayer L[DEEPIPR_WINO_MAX_LAYERS];
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const DeepiprWinoLayer &l = layers[i];
+        if (!l.W || !(l.Uf || l.Ud) || !dipr_wino_image_floats(l.Co, l.Ci))
+            return fail(DEEPIPR_EINVAL, "conv_wino_transform_multi: bad layer %d (Co, Ci multiples of 32, W and an image)", i);
+        if (!aligned16(l.W) || !aligned16(l.Uf) || !aligned16(l.Ud))
+            return fail(DEEPIPR_EINVAL, "conv_wino_transform_multi: pointers must be 16-byte aligned");
+        L[i] = DiprWinoLayer{l.W, l.Uf, l.Ud, l.Co, l.Ci};
+        bytes += static_cast<double>(l.Co) * l.Ci * (36.0 + 66.0 * ((l.Uf ? 1 : 0) + (l.Ud ? 1 : 0)));
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_CONV_WINO_WEIGHTS, st);
+    prof.bytes = bytes;
+    const bool timed = prof.a && !prof.used;
+    if (!dipr_launch_wino_weights(L, n, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_wino_transform_multi: no instance");
+    if (timed) prof.used = true;
+    return check_launch("conv_wino_transform_multi");
+}
+
+int deepipr_conv_fwd_pre(const float *x, const float *image, float *y, int N, int Ci, int Co, int H, int W, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+    if (!x || !image || !y) return fail(DEEPIPR_EINVAL, "conv_fwd_pre: null pointer");
+    const FwPlan p = plan_conv_any(N, Ci, Co, H, W, 3, 1, 1);
+    if (p.cfg < 1000 || !dipr_wino_image_floats(Co, Ci))
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_fwd_pre: this call does not take the Winograd kernel, or the weight has no image");
+    return conv_wino<false>(p, image, x, y, N, Ci, Co, H, W, static_cast<hipStream_t>(stream), "conv_fwd_pre", workspace,
+                            workspace_bytes, true);
+}
+
+int deepipr_conv_dgrad_pre(const float *dy, const float *image, float *dx, int N, int Ci, int Co, int H, int W, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    if (!dy || !image || !dx) return fail(DEEPIPR_EINVAL, "conv_dgrad_pre: null pointer");
+    const FwPlan p = plan_conv_any(N, Co, Ci, H, W, 3, 1, 1);
+    if (p.cfg < 1000 || !dipr_wino_image_floats(Co, Ci))
+        return fail(DEEPIPR_EUNSUPPORTED, "conv_dgrad_pre: this call does not take the Winograd kernel, or the weight has no image");
+    return conv_wino<true>(p, image, dy, dx, N, Co, Ci, H, W, static_cast<hipStream_t>(stream), "conv_dgrad_pre", workspace,
+                           workspace_bytes, true);
 }
 
 }  // extern "C"

@@ -16,25 +16,25 @@ inline int device_cu_count() { return dipr_device_cu_count(); }
 #include "deepipr_conv_wino.inc"
 #include "deepipr_conv_wino_wgrad.inc"
 
-template <class C, bool DGRAD>
+template <class C, bool DGRAD, bool PRE>
 void launch(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, float *ws, hipStream_t st,
             hipEvent_t a, hipEvent_t b) {
     const dim3 grid(ws ? p.grid * p.splits : p.grid), block(C::NTH);
     const int cps = ws ? p.cps : Cin / C::CK;
-    if (a) hipExtLaunchKernelGGL((k_conv_wino<C, DGRAD>), grid, block, 0, st, a, b, 0, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid,
+    if (a) hipExtLaunchKernelGGL((k_conv_wino<C, DGRAD, PRE>), grid, block, 0, st, a, b, 0, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid,
                                  cps, p.slab);
-    else hipLaunchKernelGGL((k_conv_wino<C, DGRAD>), grid, block, 0, st, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid, cps, p.slab);
+    else hipLaunchKernelGGL((k_conv_wino<C, DGRAD, PRE>), grid, block, 0, st, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid, cps, p.slab);
 }
 
-template <bool DGRAD>
+template <bool DGRAD, bool PRE>
 bool dispatch(const FwPlan &p, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H, float *ws, hipStream_t st,
               hipEvent_t a, hipEvent_t b) {
 #define DIPR_WINO(WW, TBR, NIB)                                                                                       \
     switch (p.cfg % 100) {                                                                                            \
-        case 21: launch<WnCfg<WW, TBR, NIB, 2, 1>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
-        case 22: launch<WnCfg<WW, TBR, NIB, 2, 2>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
-        case 11: launch<WnCfg<WW, TBR, NIB, 1, 1>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
-        case 12: launch<WnCfg<WW, TBR, NIB, 1, 2>, DGRAD>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 21: launch<WnCfg<WW, TBR, NIB, 2, 1>, DGRAD, PRE>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 22: launch<WnCfg<WW, TBR, NIB, 2, 2>, DGRAD, PRE>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 11: launch<WnCfg<WW, TBR, NIB, 1, 1>, DGRAD, PRE>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
+        case 12: launch<WnCfg<WW, TBR, NIB, 1, 2>, DGRAD, PRE>(p, wgt, in, out, N, Cin, M, H, ws, st, a, b); return true;  \
         default: return false;                                                                                        \
     }
     switch ((p.cfg / 100) % 10) {
@@ -79,8 +79,37 @@ FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride,
 bool dipr_launch_conv_wino(const FwPlan &p, bool dgrad, const float *wgt, const float *in, float *out, int N, int Cin, int M, int H,
                            float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b) {
     if (p.cfg < 1000) return false;
-    return dgrad ? dispatch<true>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b)
-                 : dispatch<false>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b);
+    return dgrad ? dispatch<true, false>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b)
+                 : dispatch<false, false>(p, wgt, in, out, N, Cin, M, H, ws, st, ev_a, ev_b);
+}
+
+bool dipr_launch_conv_wino_pre(const FwPlan &p, const float *image, const float *in, float *out, int N, int Cin, int M, int H,
+                               float *ws, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b) {
+    if (p.cfg < 1000 || M % 32 || Cin % 8) return false;
+    return dispatch<false, true>(p, image, in, out, N, Cin, M, H, ws, st, ev_a, ev_b);
+}
+
+size_t dipr_wino_image_floats(int Co, int Ci) {
+    if (Co <= 0 || Ci <= 0 || Co % 32 || Ci % 32) return 0;
+    return static_cast<size_t>(Ci / 8) * (Co / 32) * kWnImgBlock;          // = (Co / 8) * (Ci / 32) blocks in the other direction
+}
+
+int dipr_wino_max_layers() { return kWnXfMaxLayers; }
+
+bool dipr_launch_wino_weights(const DiprWinoLayer *layers, int n, hipStream_t st, hipEvent_t ev_a, hipEvent_t ev_b) {
+    if (n <= 0 || n > kWnXfMaxLayers) return false;
+    WnXfBatch B{};
+    B.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const DiprWinoLayer &l = layers[i];
+        if (!dipr_wino_image_floats(l.Co, l.Ci) || !l.W) return false;
+        B.L[i] = WnXfLayer{l.W, l.Uf, l.Ud, l.Co, l.Ci, blocks};
+        blocks += (l.Co / 32) * (l.Ci / 32);
+    }
+    if (ev_a) hipExtLaunchKernelGGL(k_wino_weights, dim3(blocks), dim3(256), 0, st, ev_a, ev_b, 0, B);
+    else hipLaunchKernelGGL(k_wino_weights, dim3(blocks), dim3(256), 0, st, B);
+    return true;
 }
 
 #ifdef DEEPIPR_TRACE

@@ -6,6 +6,7 @@ AlexNetPassport's (convs at 0, 2, 4, 5, 6; pools at 1, 3, 7), which is what set_
 import torch.nn as nn
 
 from deepipr_amd.models.layers.conv2d import ConvBlock
+from deepipr_amd.passport_ops import with_wino_weights
 
 # (out_channels, kernel, stride, padding) of the five conv layers; pools sit after conv 0, 1 and 4
 _CIFAR = dict(convs=[(64, 5, 1, 2), (192, 5, 1, 2), (384, 3, 1, 1), (256, 3, 1, 1), (256, 3, 1, 1)], pool=(2, 2))
@@ -37,6 +38,7 @@ class AlexNetNormal(nn.Module):
         self.features = nn.Sequential(*layers)
         self.classifier = _imagenet_head(num_classes) if big else nn.Linear(4 * 4 * width, num_classes)
 
+    @with_wino_weights
     def forward(self, x):
         x = self.features(x)
         return self.classifier(x.flatten(1))

@@ -15,7 +15,7 @@ from deepipr_amd.models._builders import (PASSPORT_TYPES, conv_factory, ind_matt
                                           trunk_sharing_enabled)
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
-from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, stage_groups
+from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, stage_groups, with_wino_weights
 
 _CUT = 5            # features[_CUT]'s input is the activation backward_stages() cuts the staged backward at
 _SHARED_CONV = os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'      # read once, at import (A/B switch)
@@ -75,6 +75,7 @@ class AlexNetPassport(nn.Module):
             x = run_layer(self.features[i], x, force_passport, ind)
         return x
 
+    @with_wino_weights
     def forward(self, x, force_passport=False, ind=0):
         layers = [m for m in self.features if isinstance(m, PASSPORT_TYPES)] if x.is_cuda else ()
         with gamma_beta_batch(layers, force_passport, ind, stage_groups(self)):     # all passport layers' gamma / beta in one GEMV launch
@@ -97,6 +98,7 @@ class AlexNetPassport(nn.Module):
                 return False
         return True
 
+    @with_wino_weights
     def forward_dual(self, x, force_passport=False):
         """-> (self(x, ind=0), self(x, ind=1)), the two forward passes of a V2 / V3 step (trainer_private.py:159-171),
         with the layers in front of the first private passport layer run ONCE (_builders.shared_trunk)."""

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from deepipr_amd import passport_ops as P
+from deepipr_amd.passport_ops import with_wino_weights
 from deepipr_amd.models.layers.conv2d import ConvBlock
 
 _STAGE_WIDTHS = (64, 128, 256, 512)
@@ -72,6 +73,7 @@ class ResNet(nn.Module):
             setattr(self, 'layer%d' % idx, nn.Sequential(*blocks))
         self.linear = nn.Linear(self.in_planes, num_classes)
 
+    @with_wino_weights
     def forward(self, x):
         out = self.convbnrelu_1(x)
         for idx in (1, 2, 3, 4):

@@ -10,6 +10,8 @@ Reference lines each operator stands in for (paths relative to kamwoh/DeepIPR):
   sign_loss           models/losses/sign_loss.py:18-54
   passport_layer      all of the above in two launches forward, two backward
 """
+import ctypes
+import functools
 import os
 import weakref
 
@@ -683,6 +685,9 @@ class HipKernels:
     def conv_algo(self):
         return ('direct', 'winograd')[_lib.lib().deepipr_conv_get_algo()]
 
+    def conv_algo_is_winograd(self):
+        return _lib.lib().deepipr_conv_get_algo() == 1
+
     _conv_wino = {}
 
     def conv_is_winograd(self, n, ci, co, h, w, k, stride, pad, direction):
@@ -724,8 +729,10 @@ class HipKernels:
             v = self._conv_ok[key] = bool(_lib.lib().deepipr_conv_supported(*key))
         return v
 
-    def conv_fwd(self, x, weight, stride, pad):
-        """conv2d(x, weight) (no bias, square kernel / stride / padding), or None when the shape is outside the kernel."""
+    def conv_fwd(self, x, weight, stride, pad, pre=None):
+        """conv2d(x, weight) (no bias, square kernel / stride / padding), or None when the shape is outside the kernel.
+        pre: the weight's (Uf, Ud) Winograd images of THIS step (wino_transform) -- taken where the call runs the Winograd
+        kernel (deepipr_conv_fwd_pre: bit-identical, the filters are not transformed again by every workgroup)."""
         n, ci, h, w = x.shape
         co, _ci, k, _k = weight.shape
         if _ci != ci or _k != k or not self.conv_supported(n, ci, co, h, w, k, stride, pad, 0):
@@ -736,9 +743,48 @@ class HipKernels:
         nbytes = self.conv_workspace(n, ci, co, h, w, k, stride, pad, 0)       # split K over workgroups: deep layers
         ws = self._scratch(dev, ('conv', st), nbytes) if nbytes else None
         with _on(dev):
-            _lib.check(_lib.lib().deepipr_conv_fwd_ws(x.data_ptr(), weight.data_ptr(), y.data_ptr(), n, ci, co, h, w, k, stride,
-                                                     pad, ws, nbytes, st), 'conv_fwd')
+            if pre is not None and pre[0] is not None and self.conv_is_winograd(n, ci, co, h, w, k, stride, pad, 0):
+                _lib.check(_lib.lib().deepipr_conv_fwd_pre(x.data_ptr(), pre[0].data_ptr(), y.data_ptr(), n, ci, co, h, w, ws,
+                                                          nbytes, st), 'conv_fwd_pre')
+            else:
+                _lib.check(_lib.lib().deepipr_conv_fwd_ws(x.data_ptr(), weight.data_ptr(), y.data_ptr(), n, ci, co, h, w, k, stride,
+                                                         pad, ws, nbytes, st), 'conv_fwd')
         return y
+
+    # ---- Winograd images of the weights, once per step (include/deepipr_hip.h: deepipr_conv_wino_transform_multi) ----
+    _wino_images = {}
+
+    def wino_image_bytes(self, co, ci):
+        return int(_lib.lib().deepipr_conv_wino_image_bytes(co, ci))
+
+    def wino_transform(self, weights, backward=True):
+        """Writes the Winograd images of `weights` ([Co][Ci][3][3], Co and Ci multiples of 32) in one launch per
+        _lib.WINO_MAX_LAYERS of them -> [(Uf, Ud or None)].  The image buffers are kept per weight address (a replayed hipGraph
+        needs them to stay put) and are valid until the weights change."""
+        out, todo = [], []
+        for w in weights:
+            co, ci = w.shape[0], w.shape[1]
+            dev = _chk(w)
+            key = (w.data_ptr(), co, ci, dev)
+            buf = self._wino_images.get(key)
+            nfl = self.wino_image_bytes(co, ci) // 4
+            if buf is None:
+                buf = self._wino_images[key] = [torch.empty(nfl, dtype=torch.float32, device=dev), None]
+            if backward and buf[1] is None:
+                buf[1] = torch.empty(nfl, dtype=torch.float32, device=dev)
+            out.append((buf[0], buf[1] if backward else None))
+            todo.append((w, buf[0], buf[1] if backward else None, co, ci, dev))
+        for lo in range(0, len(todo), _lib.WINO_MAX_LAYERS):
+            chunk = todo[lo:lo + _lib.WINO_MAX_LAYERS]
+            arr = (_lib.WinoLayer * len(chunk))()
+            for i, (w, uf, ud, co, ci, _dev) in enumerate(chunk):
+                arr[i] = _lib.WinoLayer(w.data_ptr(), uf.data_ptr(), _p(ud), co, ci)
+            dev = chunk[0][5]
+            with _on(dev):
+                _lib.check(_lib.lib().deepipr_conv_wino_transform_multi(ctypes.addressof(arr), len(chunk), _stream(dev)),
+                           'conv_wino_transform_multi')
+        return out
+
 
     _conv_ws = {}
 
@@ -750,8 +796,9 @@ class HipKernels:
             v = self._conv_ws[key] = int(_lib.lib().deepipr_conv_workspace_bytes(*key))
         return v
 
-    def conv_dgrad(self, dy, weight, x_shape, stride, pad):
-        """Gradient of conv2d(x, weight) with respect to x, or None when the shape is outside the kernel."""
+    def conv_dgrad(self, dy, weight, x_shape, stride, pad, pre=None):
+        """Gradient of conv2d(x, weight) with respect to x, or None when the shape is outside the kernel.  pre: as conv_fwd
+        (the backward-data image Ud written before the forward pass of the same step)."""
         n, ci, h, w = x_shape
         co, _ci, k, _k = weight.shape
         if _ci != ci or _k != k or not self.conv_supported(n, ci, co, h, w, k, stride, pad, 1):
@@ -762,8 +809,12 @@ class HipKernels:
         nbytes = self.conv_workspace(n, ci, co, h, w, k, stride, pad, 1)
         ws = self._scratch(dev, ('conv', st), nbytes) if nbytes else None
         with _on(dev):
-            _lib.check(_lib.lib().deepipr_conv_dgrad_ws(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, ci, co, h, w, k,
-                                                       stride, pad, ws, nbytes, st), 'conv_dgrad')
+            if pre is not None and pre[1] is not None and self.conv_is_winograd(n, ci, co, h, w, k, stride, pad, 1):
+                _lib.check(_lib.lib().deepipr_conv_dgrad_pre(dy.data_ptr(), pre[1].data_ptr(), dx.data_ptr(), n, ci, co, h, w, ws,
+                                                            nbytes, st), 'conv_dgrad_pre')
+            else:
+                _lib.check(_lib.lib().deepipr_conv_dgrad_ws(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, ci, co, h, w, k,
+                                                           stride, pad, ws, nbytes, st), 'conv_dgrad')
         return dx
 
     def sgd_chunk(self):
@@ -919,6 +970,14 @@ class _SignLoss(torch.autograd.Function):
 # DEEPIPR_OWN_WGRAD=0 switches only the weight gradient off.  All three are bit-reproducible.
 OWN_CONV = os.environ.get('DEEPIPR_OWN_CONV', 'auto')
 OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0' and OWN_CONV != '0'
+# the pre-transformed form of the Winograd forward / backward-data kernels (wino_weights): on; and for weights of at most this
+# many filters (Co * Ci)
+WINO_PRE = os.environ.get('DEEPIPR_WINO_PRE', '1') != '0' and OWN_CONV != '0'
+WINO_PRE_MAX_FILTERS = int(os.environ.get('DEEPIPR_WINO_PRE_MAX_FILTERS', 1 << 30))
+# ... and from this batch size up: the one transform launch per step (138 MB written for ResNet18) is paid back by the 26
+# convolution launches only when they are long enough (measured, bench.py replay: config R 128 images -0.6 %, V3 66 + 66
+# stacked -4.4 %, AlexNet 64 -1 %; config-P shard 32 images +0.9 %: off)
+WINO_PRE_MIN_BATCH = int(os.environ.get('DEEPIPR_WINO_PRE_MIN_BATCH', 48))
 
 
 _OWN_CONV_FROM_ENV = 'DEEPIPR_OWN_CONV' in os.environ
@@ -1011,15 +1070,20 @@ def _own_wgrad(x_in, w, stride, pad):
     return bool(kernels.conv_wgrad_workspace(n, ci, w.shape[0], h, wd, w.shape[2], w.shape[3], stride, pad))
 
 
-def _conv_fwd(x_in, w, stride, pad):
+def _conv_fwd(x_in, w, stride, pad, ctx=None):
+    """The data convolution of a node's forward.  ctx: the node -- it keeps the weight's Winograd images of this step
+    (_wino_pre; None outside wino_weights()) for its backward-data pass."""
+    pre = _wino_pre(w)
+    if ctx is not None:
+        ctx.wino_pre = pre
     if _own_fwd(x_in, w, stride, pad):
-        return kernels.conv_fwd(x_in, w, stride, pad)
+        return kernels.conv_fwd(x_in, w, stride, pad, pre)
     return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
 
 
-def _conv_dgrad(dconv, x_in, w, stride, pad):
+def _conv_dgrad(dconv, x_in, w, stride, pad, pre=None):
     if _own_dgrad(x_in.shape, w, stride, pad, dconv):
-        return kernels.conv_dgrad(dconv, w, x_in.shape, stride, pad)
+        return kernels.conv_dgrad(dconv, w, x_in.shape, stride, pad, pre)
     return torch.ops.aten.convolution_backward(dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0],
                                                1, [True, False, False])[0]
 
@@ -1036,17 +1100,18 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
         return None, None, False
     if need_dw and _own_wgrad(x_in, w, stride, pad):
         dconv = dconv.contiguous()
-        dx = _conv_dgrad(dconv, x_in, w, stride, pad) if need_dx else None
         if w.shape[1] % 32 == 0:                       # (every instance but the 3-channel stem's adds the rank-2 term in its reduction)
-            return dx, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m), False
-        # the 3-channel stem instance has no fused rank-2 term: the separate accumulate pass
-        return dx, kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad)), False
+            dw = kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m)
+        else:                                          # the 3-channel stem instance has no fused rank-2 term: the separate accumulate pass
+            dw = kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad))
+        dx = _conv_dgrad(dconv, x_in, w, stride, pad, getattr(ctx, 'wino_pre', None)) if need_dx else None
+        return dx, dw, False
     own_dx = need_dx and _own_dgrad(x_in.shape, w, stride, pad, dconv)
     dx, dw, _ = torch.ops.aten.convolution_backward(
         dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
         [need_dx and not own_dx, need_dw, False])
     if own_dx:
-        dx = kernels.conv_dgrad(dconv.contiguous(), w, x_in.shape, stride, pad)
+        dx = kernels.conv_dgrad(dconv.contiguous(), w, x_in.shape, stride, pad, getattr(ctx, 'wino_pre', None))
     if need_dw:
         dw = dw.contiguous()
         if defer is not None:
@@ -1154,7 +1219,7 @@ class _Conv2dOwn(torch.autograd.Function):
         ctx.geom = (stride, pad)
         ctx.share = share                          # StackShare: may carry the private branch's (dgamma, dbeta, m) at backward time
         ctx.set_materialize_grads(False)
-        return _conv_fwd(x, w, stride, pad)
+        return _conv_fwd(x, w, stride, pad, ctx)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1176,7 +1241,7 @@ class _Conv2dOwn(torch.autograd.Function):
                 dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad)
             need_dw = False
         if need_dx and _own_dgrad(x.shape, w, stride, pad, dy):
-            dx = kernels.conv_dgrad(dy, w, x.shape, stride, pad)
+            dx = kernels.conv_dgrad(dy, w, x.shape, stride, pad, getattr(ctx, 'wino_pre', None))
             need_dx = False
         if need_dx or need_dw:
             vdx, vdw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [1, 1], False,
@@ -1282,7 +1347,7 @@ class _PassportLayer(torch.autograd.Function):
         x_in = None
         if conv_inside:                               # no norm between conv and affine: the data conv runs in this node
             x_in = xhat
-            xhat = _conv_fwd(x_in, weight, stride, pad)
+            xhat = _conv_fwd(x_in, weight, stride, pad, ctx)
         bb = None if b is None else b.contiguous().view(-1)
         y, gamma, beta, loss, acc, bits = kernels.passport_fwd(xhat, weight, m, bb, float(alpha), relu)
         ctx.save_for_backward(xhat, weight, gamma, beta, m, bb, x_in)
@@ -1337,7 +1402,7 @@ class _PassportBNLayer(torch.autograd.Function):
         x_in = None
         if conv is not None:
             x_in = x
-            x = _conv_fwd(x_in, w, stride, pad)
+            x = _conv_fwd(x_in, w, stride, pad, ctx)
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)
@@ -1491,6 +1556,69 @@ def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, 
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
+_WINO_CONVS = weakref.WeakKeyDictionary()      # model -> its 3x3 stride-1 convolutions that have a Winograd image
+_WINO_TABLE = None        # {weight address: (weight shape, Uf, Ud)} while a net's forward pass is under wino_weights()
+
+
+def _wino_pre(w):
+    """(Uf, Ud) of this weight for the current forward pass, or None."""
+    if _WINO_TABLE is None:
+        return None
+    hit = _WINO_TABLE.get(w.data_ptr())
+    return hit[1:] if hit is not None and hit[0] == tuple(w.shape) else None
+
+
+class wino_weights:
+    """Context manager for a net's forward pass: the Winograd images U = G g G^T of ALL its 3x3 stride-1 convolutions' weights
+    in ONE launch up front (kernels.wino_transform -> deepipr_conv_wino_transform_multi), so that the forward and -- through
+    the autograd nodes, which keep the pair -- the backward-data kernels of this step copy them global -> LDS instead of
+    transforming the same filters in every workgroup.  The weights must not change between the forward pass
+    and its backward pass (autograd's own rule for saved tensors); the images are rewritten by the next forward pass.  A
+    replayed hipGraph contains the transform launch like any other kernel of the step.
+    DEEPIPR_WINO_PRE=0 switches it off (every workgroup transforms its filters itself: bit-identical results)."""
+
+    def __init__(self, model, x):
+        self.model = model
+        self.on = bool(x.is_cuda) and WINO_PRE and x.shape[0] >= WINO_PRE_MIN_BATCH and kernels.conv_algo_is_winograd()
+
+    def _convs(self):
+        convs = _WINO_CONVS.get(self.model)
+        if convs is None:
+            convs = _WINO_CONVS[self.model] = [
+                m for m in self.model.modules()
+                if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                and m.groups == 1 and m.dilation == (1, 1) and m.bias is None and m.padding_mode == 'zeros'
+                and m.in_channels % 32 == 0 and m.out_channels % 32 == 0]
+        return convs
+
+    def __enter__(self):
+        global _WINO_TABLE
+        self.before = _WINO_TABLE
+        if not self.on or self.before is not None:          # (a nested forward keeps the outer table)
+            return self
+        ws = [m.weight for m in self._convs() if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
+              and 0 < WINO_PRE_MAX_FILTERS >= m.weight.shape[0] * m.weight.shape[1]]
+        if ws:
+            with torch.no_grad():
+                imgs = kernels.wino_transform([w.detach() for w in ws], backward=torch.is_grad_enabled())
+            _WINO_TABLE = {w.data_ptr(): (tuple(w.shape),) + pair for w, pair in zip(ws, imgs)}
+        return self
+
+    def __exit__(self, *exc):
+        global _WINO_TABLE
+        _WINO_TABLE = self.before
+        return False
+
+
+def with_wino_weights(forward):
+    """Decorator for a net's forward(self, x, ...) / forward_dual: the whole pass under wino_weights(self, x)."""
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        with wino_weights(self, x):
+            return forward(self, x, *args, **kwargs)
+    return wrapped
+
+
 class gamma_beta_batch:
     """Context manager for a net's forward: gamma / beta of ALL its passport layers that will take the fused BatchNorm
     form in ONE launch (deepipr_gamma_beta_fwd_multi) instead of one GEMV launch per layer -- ResNet18: the five
@@ -1635,7 +1763,7 @@ class _PassportGNLayer(torch.autograd.Function):
         x_in = None
         if conv_inside:                               # the data convolution runs inside this node (see _PassportBNLayer)
             x_in = x
-            x = _conv_fwd(x_in, w, stride, pad)
+            x = _conv_fwd(x_in, w, stride, pad, ctx)
         gi = None if gamma_in is None else gamma_in.contiguous().view(-1)
         bi = None if beta_in is None else beta_in.contiguous().view(-1)
         bb = None if b is None else b.contiguous().view(-1)

@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 9
+#define DEEPIPR_ABI_VERSION 10
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -88,7 +88,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_WINO_FWD 27      /* Winograd F(2x2, 3x3) forward: EXECUTED FLOPs (the direct sum's / 2.25) */
 #define DEEPIPR_K_CONV_WINO_DGRAD 28
 #define DEEPIPR_K_CONV_WINO_WGRAD 29     /* Winograd F(3x3, 2x2) weight gradient: EXECUTED FLOPs */
-#define DEEPIPR_PROFILE_KERNELS 30
+#define DEEPIPR_K_CONV_WINO_WEIGHTS 30   /* the Winograd weight transform of the pre-transformed form (bytes: 36 in + 66 out per filter and direction) */
+#define DEEPIPR_PROFILE_KERNELS 31
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -508,6 +509,36 @@ int deepipr_conv_fwd_ws(const float *x, const float *w, float *y, int N, int Ci,
                         void *workspace, size_t workspace_bytes, void *stream);
 int deepipr_conv_dgrad_ws(const float *dy, const float *w, float *dx, int N, int Ci, int Co, int H, int W, int k, int stride,
                           int pad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Pre-transformed form of the Winograd forward / backward-data convolution (ABI v10).  In deepipr_conv_fwd_ws / _dgrad_ws every
+ * workgroup transforms the filters it stages (G g G^T: the same arithmetic 1 000 times per launch of a 64-channel layer at
+ * batch 128, and the costliest part of the main loop beside the MFMAs).  Here the transform runs ONCE per step:
+ *   deepipr_conv_wino_transform_multi  writes, for up to deepipr_conv_wino_max_layers() weights [Co][Ci][3][3] per launch, the
+ *       image Uf (forward: rows = co) and / or Ud (backward-data: rows = ci, filters rotated by 180 degrees) -- each
+ *       deepipr_conv_wino_image_bytes(Co, Ci) bytes (66 B per filter; 0: Co or Ci is not a multiple of 32, no such form), laid
+ *       out as the kernels' LDS stage: [chunk of 8 input channels][row / 32][32 rows][U[row][xi][c][nu], 128 floats + 4 of pitch];
+ *   deepipr_conv_fwd_pre / _dgrad_pre  are deepipr_conv_fwd_ws / _dgrad_ws of a 3x3 stride-1 pad-1 convolution with the image
+ *       in place of w: a chunk's rows go global -> LDS by global_load_lds_dwordx4 (no registers, no vector instructions, no LDS
+ *       stores for the weights).  Same shapes, same workspace (deepipr_conv_workspace_bytes), same planner; results BIT-IDENTICAL
+ *       to the _ws entry points (one definition of the transform's arithmetic).  DEEPIPR_EUNSUPPORTED where the call of this shape
+ *       would not take the Winograd kernel (deepipr_conv_algo_of) or the weight has no image.
+ * The images belong to the caller and must be rewritten whenever the weights change (the train step: once, before the
+ * forward pass; the backward pass of the same step reads Ud).
+ * replaces: nothing of the reference's own -- `self.conv(x)` (models/layers/passportconv2d.py:218, models/layers/conv2d.py:31)
+ *           is one ATen call there; this is the same convolution with the filter transform hoisted out of the launch. */
+#define DEEPIPR_WINO_MAX_LAYERS 24
+typedef struct DeepiprWinoLayer {
+    const float *W;          /* [Co][Ci][3][3] */
+    float *Uf, *Ud;          /* images out; either may be NULL */
+    int Co, Ci;
+} DeepiprWinoLayer;
+size_t deepipr_conv_wino_image_bytes(int Co, int Ci);
+int deepipr_conv_wino_max_layers(void);
+int deepipr_conv_wino_transform_multi(const DeepiprWinoLayer *layers, int n, void *stream);
+int deepipr_conv_fwd_pre(const float *x, const float *image, float *y, int N, int Ci, int Co, int H, int W, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int deepipr_conv_dgrad_pre(const float *dy, const float *image, float *dx, int N, int Ci, int Co, int H, int W, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

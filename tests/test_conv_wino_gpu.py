@@ -65,6 +65,16 @@ def test_winograd_forward_and_backward_data_match_the_float64_oracle(K, shape):
     ref = _dgrad64(dy, x, wt)
     assert float((dx.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, 1, 1))
+    # the pre-transformed form (deepipr_conv_wino_transform_multi + deepipr_conv_fwd_pre / _dgrad_pre: the filters' images
+    # G g G^T written once, rows copied global -> LDS): the same arithmetic, so the same bits
+    if ci % 32 == 0 and co % 32 == 0:
+        assert K.wino_image_bytes(co, ci) == co * ci * 66
+        pre = K.wino_transform([wt])[0]
+        assert torch.equal(y, K.conv_fwd(x, wt, 1, 1, pre)) and torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, 1, 1, pre))
+        fwd_only = K.wino_transform([wt], backward=False)[0]
+        assert fwd_only[1] is None and torch.equal(y, K.conv_fwd(x, wt, 1, 1, fwd_only))
+    else:
+        assert K.wino_image_bytes(co, ci) == 0
 
 
 @pytest.mark.parametrize('form', ['2,1,1', '1,1,1', '1,2,1', '2,2,1', '1,2,4', '2,1,2', '1,1,8'])
@@ -90,6 +100,8 @@ def test_every_instance_of_the_family(shape, form):
             '[0, 0], 1, [True, False, False])[0]\n'
             'assert float((dx.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "dgrad"\n'
             'assert torch.equal(y, K.conv_fwd(x, wt, 1, 1)) and torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, 1, 1))\n'
+            'pre = K.wino_transform([wt])[0]\n'
+            'assert torch.equal(y, K.conv_fwd(x, wt, 1, 1, pre)) and torch.equal(dx, K.conv_dgrad(dy, wt, x.shape, 1, 1, pre)), "pre"\n'
             'print("ok")\n') % (shape,)
     env = dict(os.environ, DEEPIPR_WINO_FORM=form, DEEPIPR_CONV_ALGO='winograd')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -148,3 +160,49 @@ def test_every_tap_and_every_pixel(K):
                 assert torch.equal(y.double(), _conv64(x, w)), (hw, r, s)
                 dx = K.conv_dgrad(dy, w, x.shape, 1, 1)
                 assert torch.equal(dx.double(), _dgrad64(dy, x, w)), (hw, r, s)
+
+
+def test_weight_images_of_many_layers_in_one_launch(K):
+    """deepipr_conv_wino_transform_multi with more layers than one launch takes (24), mixed sizes: every image equals the one
+    a single-layer call writes; the images of a weight keep their addresses from call to call (a replayed hipGraph reads
+    them)."""
+    ws = [_rand((co, ci, 3, 3), 100 + i, 0.1) for i, (co, ci) in enumerate([(64, 64), (128, 64), (32, 96), (256, 128)] * 7)]
+    many = K.wino_transform(ws)
+    for w, (uf, ud) in zip(ws, many):
+        keep = (uf.clone(), ud.clone(), uf.data_ptr(), ud.data_ptr())
+        uf.zero_()
+        ud.zero_()
+        one = K.wino_transform([w])[0]
+        assert one[0].data_ptr() == keep[2] and one[1].data_ptr() == keep[3]
+        co, ci = w.shape[:2]
+        rows = lambda img: img.view(-1, 132)[:, :128]          # (the 4 floats of pitch per row are never written)
+        assert torch.equal(rows(one[0]), rows(keep[0])) and torch.equal(rows(one[1]), rows(keep[1]))
+        assert float(rows(one[0]).abs().sum()) > 0
+
+
+def test_a_train_step_with_and_without_the_weight_images_is_bit_identical(K):
+    """ResNet18 V1 step (forward, backward, SGD) with DEEPIPR_WINO_PRE on (wino_weights: one transform launch per step, the
+    Winograd forward / backward-data kernels read the images) and off (every workgroup transforms its filters): the same
+    losses and the same parameters after two steps, bit for bit."""
+    from deepipr_amd import passport_ops as P
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from tests.gpu_common import pinned_miopen
+    from tests.test_parity_gpu import _fullsize_pair
+    from oracle.cases import SGD
+    runs = []
+    before = P.WINO_PRE
+    try:
+        for pre in (True, False):
+            P.WINO_PRE = pre
+            prod, _ref, x, y = _fullsize_pair(False, 32, 10)
+            x, y = x.to(DEV), y.to(DEV)
+            opt = torch.optim.SGD(prod.parameters(), **SGD)
+            with pinned_miopen():
+                outs = [[float(v) for v in train_step_v1(prod, opt, x, y)] for _ in range(2)]
+            torch.cuda.synchronize()
+            runs.append((outs, {k: v.clone() for k, v in prod.state_dict().items()}))
+    finally:
+        P.WINO_PRE = before
+    assert runs[0][0] == runs[1][0]
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
