@@ -714,8 +714,11 @@ def main():
                  # the kernel pair the north star names: gamma / beta of ALL passport layers in one launch (W read once,
                  # 4 B/weight) and the rank-2 update accumulated into each layer's wgrad (8 B/weight, one launch per layer)
                  'gamma_beta_fwd': 'passport GEMV, all passport layers in one launch: gamma, beta = W . pooled keys (4 B/weight)',
-                 'gamma_beta_bwd': 'passport rank-2 update accumulated into the conv wgrad (8 B/weight)'}
-    NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd')
+                 'gamma_beta_bwd': 'passport rank-2 update accumulated into the conv wgrad (8 B/weight)',
+                 # pre-transformed form of the Winograd forward / backward-data kernels: ONE launch per step writes the images
+                 # G g G^T of every 3x3 stride-1 weight (36 B in, 66 B out per filter and direction)
+                 'conv_wino_weights': 'Winograd weight transform, all 3x3 stride-1 layers in one launch (36 B in + 2 x 66 B out per filter)'}
+    NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd', 'conv_wino_weights')
     hbm = None
     if out['exchange_timeouts']:
         out['roofline_refused'] = ('an in-launch exchange of the single-pass kernels timed out (%d buffer(s)): their '

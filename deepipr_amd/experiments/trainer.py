@@ -136,11 +136,13 @@ class Tester(object):
 
 
 class StepRunner:
-    """Runs step_fn eagerly, or -- graph=True, fixed batch shape -- from hipGraphs captured on the first full batch;
-    ragged last batches fall back to the eager step.
+    """Runs step_fn eagerly, or -- graph=True -- from hipGraphs captured on the first batch of each shape (one GPU: up to
+    MAX_SHAPES further shapes, i.e. the ragged last batch too; data parallel: the first shape, others take the eager step).
       one GPU      : the whole step, optimiser included, is one graph (experiments/graph_step.py);
       data parallel: the staged form (experiments/staged.py) -- forward + backward as a few graphs cut at the gradient
                      buckets' boundaries, each bucket's RCCL all-reduce launched between the replays, one fused SGD."""
+
+    MAX_SHAPES = 3
 
     def __init__(self, step_fn, model, optimizer, graph=False):
         self.step_fn, self.model, self.optimizer = step_fn, model, optimizer
@@ -151,6 +153,7 @@ class StepRunner:
             passport_ops.prefer_own_kernels()                  # every rank on the same, bit-reproducible kernels
         self._graphed = None
         self._shape = None
+        self._others = {}                  # one GPU: (data shape, target shape) -> graph of a further batch shape
         self._probe = None                 # staged data-parallel step: (replays left to watch, state to fall back to)
 
     def _build(self, data, target):
@@ -175,8 +178,18 @@ class StepRunner:
                 # poisoned output reaches the caller's meters (three watched replays lost two batches).
                 self._probe = [1, {k: v.clone() for k, v in self.model.state_dict().items()}, self.optimizer.flat_buf.clone()]
             return self._watched(self._graphed(data, target), data, target)      # capture does not execute: replay the first batch
-        if (tuple(data.shape), tuple(target.shape)) != self._shape:
-            return self.step_fn(self.model, self.optimizer, data, target)
+        key = (tuple(data.shape), tuple(target.shape))
+        if key != self._shape:
+            # another batch shape (the ragged last batch of an epoch): on one GPU it gets a graph of its own -- FlatSGD keeps
+            # a chunk table per capture, the norm layers' statistics and the parameters are the same tensors -- instead of the
+            # host-bound eager step (2-3x the replayed step's time); a data-parallel run keeps the eager step for it (the staged
+            # form's buckets and events belong to one shape)
+            if self.distributed or len(self._others) >= self.MAX_SHAPES and key not in self._others:
+                return self.step_fn(self.model, self.optimizer, data, target)
+            g = self._others.get(key)
+            if g is None:
+                g = self._others[key] = self._build(data, target)
+            return g(data, target)
         return self._watched(self._graphed(data, target), data, target)
 
     def _watched(self, out, data, target):

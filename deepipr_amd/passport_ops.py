@@ -1599,8 +1599,9 @@ class wino_weights:
         ws = [m.weight for m in self._convs() if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
               and 0 < WINO_PRE_MAX_FILTERS >= m.weight.shape[0] * m.weight.shape[1]]
         if ws:
+            backward = torch.is_grad_enabled()           # (the backward-data images only when a backward pass can follow)
             with torch.no_grad():
-                imgs = kernels.wino_transform([w.detach() for w in ws], backward=torch.is_grad_enabled())
+                imgs = kernels.wino_transform([w.detach() for w in ws], backward=backward)
             _WINO_TABLE = {w.data_ptr(): (tuple(w.shape),) + pair for w, pair in zip(ws, imgs)}
         return self
 

@@ -850,15 +850,16 @@ def test_graphed_step_equals_eager_step():
 
 @pytest.mark.miopen_pinned
 def test_trainer_graph_mode_equals_eager_epoch():
-    """Trainer(graph=True): captured on the first batch (without advancing training), replayed for full
-    batches, eager for the ragged last one -- same epoch result and weights as the eager Trainer."""
+    """Trainer(graph=True): captured on the first batch of each shape (without advancing training) and replayed -- the ragged
+    batch gets a graph of its own (StepRunner._others), captured on its first occurrence and replayed on its second -- same
+    epoch result and weights as the eager Trainer."""
     from deepipr_amd.experiments.trainer import Trainer
     from deepipr_amd.flat_sgd import FlatSGD
     outs = []
     for graph, flat in ((False, False), (True, False), (True, True)):
         prod, _ref, x, y = _fullsize_pair(False, 32, 10)
         x, y = x.to(DEV), y.to(DEV)
-        loader = [(x, y), (x.flip(0), y.flip(0)), (x * 0.5, y), (x[:20], y[:20])]
+        loader = [(x, y), (x.flip(0), y.flip(0)), (x[:20], y[:20]), (x * 0.5, y), (x[:20].flip(0), y[:20].flip(0))]
         opt = (FlatSGD if flat else torch.optim.SGD)(prod.parameters(), **SGD)
         bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
         torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
