@@ -3,7 +3,7 @@
 # (DEEPIPR_WINO_FORM, measurement knob of plan_conv_wino) over the four ResNet18 shapes at batch 128 -> gpurun_out/wino_forms.jsonl
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; : > gpurun_out/wino_forms.jsonl
-for f in default 1,2,1 2,2,1 2,2,2 1,2,2 2,1,2 1,1,2 2,1,1 1,1,1 2,2,4 1,2,4; do
+for f in ${FORMS:-default 1,2,1 2,2,1 2,2,2 1,2,2 2,1,2 1,1,2 2,1,1 1,1,1 2,2,4 1,2,4}; do
   if [ $f = default ]; then unset DEEPIPR_WINO_FORM; else export DEEPIPR_WINO_FORM=$f; fi
   WHATIF_MASK=0 timeout 300 python tools/wino_whatif.py | grep '^{' | sed "s/^{/{\"form\": \"$f\", /" | tee -a gpurun_out/wino_forms.jsonl
 done
