@@ -10,7 +10,7 @@ CMD="python $GRAFT_REPO_ROOT/bench.py --eager --steps 12 --warmup 4 --no-cpu-bas
 $CMD > gpurun_out/${R}_bench_eager_for_pmc.log 2>&1
 grep '"metric"' gpurun_out/${R}_bench_eager_for_pmc.log > gpurun_out/${R}_bench_eager_for_pmc.json
 cd /tmp
-KEEP='k_bn_res|k_bn_dual|k_gamma_beta|k_rank2|k_sgd|k_bn_affine|k_bn_walk|k_gn_|k_conv'
+KEEP='k_bn_res|k_bn_dual|k_gamma_beta|k_rank2|k_sgd|k_bn_affine|k_bn_walk|k_gn_|k_conv|k_wino'
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- $CMD --no-kernel-timing > /tmp/pmc_$c.log 2>&1
