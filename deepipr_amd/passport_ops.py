@@ -759,8 +759,9 @@ class HipKernels:
 
     def wino_transform(self, weights, backward=True):
         """Writes the Winograd images of `weights` ([Co][Ci][3][3], Co and Ci multiples of 32) in one launch per
-        _lib.WINO_MAX_LAYERS of them -> [(Uf, Ud or None)].  The image buffers are kept per weight address (a replayed hipGraph
-        needs them to stay put) and are valid until the weights change."""
+        _lib.WINO_MAX_LAYERS of them -> [(Uf, Ud or None)].  The image buffers are kept per weight address for as long as the
+        weight tensor OBJECT passed here lives (a replayed hipGraph needs them to stay put: pass the parameters themselves, not
+        temporaries) and are valid until the weights change."""
         out, todo = [], []
         for w in weights:
             co, ci = w.shape[0], w.shape[1]
@@ -770,6 +771,7 @@ class HipKernels:
             nfl = self.wino_image_bytes(co, ci) // 4
             if buf is None:
                 buf = self._wino_images[key] = [torch.empty(nfl, dtype=torch.float32, device=dev), None]
+                weakref.finalize(w, self._wino_images.pop, key, None)        # the images go when the weight tensor goes
             if backward and buf[1] is None:
                 buf[1] = torch.empty(nfl, dtype=torch.float32, device=dev)
             out.append((buf[0], buf[1] if backward else None))
@@ -1601,7 +1603,7 @@ class wino_weights:
         if ws:
             backward = torch.is_grad_enabled()           # (the backward-data images only when a backward pass can follow)
             with torch.no_grad():
-                imgs = kernels.wino_transform([w.detach() for w in ws], backward=backward)
+                imgs = kernels.wino_transform(ws, backward=backward)
             _WINO_TABLE = {w.data_ptr(): (tuple(w.shape),) + pair for w, pair in zip(ws, imgs)}
         return self
 
