@@ -141,3 +141,20 @@ def test_conv_wgrad_planner_and_argument_checks_without_a_gpu():
     assert ws(128, 64, 128, 32, 32, 1, 1, 2, 0) % (64 * 64 * 4) == 0
     rc = handle.deepipr_conv_wgrad(None, None, None, 128, 64, 64, 32, 32, 3, 3, 1, 1, None, None, None, None, 0, None)
     assert rc == -1 and b'conv_wgrad' in handle.deepipr_last_error()
+
+
+def test_wino_image_geometry_and_argument_checks_without_a_gpu():
+    """The pre-transformed Winograd form (ABI v10): 66 bytes per filter and direction for weights whose channel counts are
+    multiples of 32, no such form otherwise; argument validation happens before any HIP call."""
+    handle = _lib.lib()
+    size = handle.deepipr_conv_wino_image_bytes
+    assert size(64, 64) == 64 * 64 * 66 and size(512, 256) == 512 * 256 * 66 and size(32, 96) == 32 * 96 * 66
+    for co, ci in [(64, 3), (48, 64), (64, 40), (0, 64), (64, -32)]:
+        assert size(co, ci) == 0, (co, ci)
+    assert handle.deepipr_conv_wino_max_layers() == _lib.WINO_MAX_LAYERS
+    assert handle.deepipr_conv_wino_transform_multi(None, 1, None) == -1 and b'conv_wino_transform_multi' in handle.deepipr_last_error()
+    one = (_lib.WinoLayer * 1)(_lib.WinoLayer(16, 0, 0, 64, 64))                     # a weight but no image to write
+    assert handle.deepipr_conv_wino_transform_multi(ctypes.addressof(one), 1, None) == -1
+    assert handle.deepipr_conv_wino_transform_multi(ctypes.addressof(one), _lib.WINO_MAX_LAYERS + 1, None) == -1
+    assert handle.deepipr_conv_fwd_pre(None, None, None, 8, 64, 64, 8, 8, None, 0, None) == -1
+    assert handle.deepipr_conv_dgrad_pre(None, None, None, 8, 64, 64, 8, 8, None, 0, None) == -1
