@@ -56,6 +56,7 @@ SIGNATURES = {
     'deepipr_ce_top1_workspace_bytes': (_sz, [_int]),
     'deepipr_ce_top1_fwd': (_int, [_f32p, _vp, _int, _int, _f32p, _f32p, _f32p, _vp, _vp]),
     'deepipr_ce_bwd': (_int, [_f32p, _f32p, _vp, _f32p, _int, _int, _f32p, _vp]),
+    'deepipr_scalar_sums': (_int, [_vp, _int, _int, _f32p, _vp]),
     'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd2': (_int, [_f32p, _f32p, _f32p, _f32p, _sz, _vp]),

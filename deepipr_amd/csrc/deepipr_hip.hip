@@ -2689,6 +2689,24 @@ __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float *__restrict__ d
 // One 12 B/elt pass instead of ATen's add (12 B/elt) + relu (8 B/elt); backward is one masked copy shared by
 // both inputs: d = dy * [out > 0].
 // ============================================================================================
+// The step's scalar bookkeeping in one launch: out[0] = t[0] + ... + t[na-1], out[1] = t[na] + ... + t[na+nb-1] (both left to
+// right, as the chain of aten::add the reference's `loss + sign_loss` loops are, trainer.py:140-145 / trainer_private.py:163-173),
+// out[2] = out[0] + out[1].  Ten 5-us launches of one-element adds per V2 step otherwise.
+constexpr int kScalarTermsMax = 48;
+struct ScalarTerms {
+    const float *p[kScalarTermsMax];
+    int na, nb;
+};
+__global__ void k_scalar_sums(ScalarTerms T, float *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < T.na; ++i) a = i ? a + *T.p[i] : *T.p[i];
+    for (int i = 0; i < T.nb; ++i) b = i ? b + *T.p[T.na + i] : *T.p[T.na + i];
+    out[0] = a;
+    out[1] = b;
+    out[2] = T.na && T.nb ? a + b : (T.na ? a : b);
+}
+
 __global__ __launch_bounds__(kThreads) void k_add_relu_fwd(const float *__restrict__ a, const float *__restrict__ b,
                                                            float *__restrict__ out, size_t n) {
     const size_t step = static_cast<size_t>(gridDim.x) * kThreads;
@@ -4035,6 +4053,20 @@ int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *tar
     hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(static_cast<size_t>(N) * C)), dim3(kThreads), 0, st, dloss, logits,
                        target, lse, N, C, dlogits);
     return check_launch("ce_bwd");
+}
+
+int deepipr_scalar_sums(const float *const *terms, int n_a, int n_b, float *out, void *stream) {
+    if (!terms || !out || n_a < 0 || n_b < 0 || n_a + n_b <= 0 || n_a + n_b > kScalarTermsMax)
+        return fail(DEEPIPR_EINVAL, "scalar_sums: 1..%d terms", kScalarTermsMax);
+    ScalarTerms T{};
+    T.na = n_a;
+    T.nb = n_b;
+    for (int i = 0; i < n_a + n_b; ++i) {
+        if (!terms[i]) return fail(DEEPIPR_EINVAL, "scalar_sums: null term %d", i);
+        T.p[i] = terms[i];
+    }
+    hipLaunchKernelGGL(k_scalar_sums, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), T, out);
+    return check_launch("scalar_sums");
 }
 
 int deepipr_add_relu_fwd(const float *a, const float *b, float *out, size_t n, void *stream) {

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from deepipr_amd.models.losses.sign_loss import SignLoss
-from deepipr_amd.passport_ops import cross_entropy_top1
+from deepipr_amd.passport_ops import cross_entropy_top1, scalar_sums
 
 
 def accuracy(output, target, topk=(1,)):
@@ -40,6 +40,11 @@ def total_sign_loss(model, device):
         if isinstance(m.loss, torch.Tensor):
             total = m.loss if total is None else total + m.loss
     return total if total is not None else torch.zeros((), device=device)
+
+
+def sign_loss_terms(model):
+    """The SignLoss modules' losses of the last forward pass, in module order (the order total_sign_loss adds them in)."""
+    return [m.loss for m in sign_loss_modules(model) if isinstance(m.loss, torch.Tensor)]
 
 
 def mean_sign_acc(model, device):
@@ -76,8 +81,10 @@ def forward_loss_v1(model, data, target):
     reset_sign_losses(model)
     pred = model(data)
     loss, top1 = cross_entropy_top1(pred, target)          # F.cross_entropy + accuracy()[0], one fused launch on the GPU
-    sign_loss = total_sign_loss(model, data.device)
-    return loss + sign_loss, (loss.detach(), sign_loss.detach(), top1)
+    _ce, sign_loss, objective = scalar_sums([loss], sign_loss_terms(model))      # sign_loss += m.loss ...; loss + sign_loss: ONE launch
+    if sign_loss is None:
+        sign_loss = torch.zeros((), device=data.device)
+    return objective, (loss.detach(), sign_loss.detach(), top1)
 
 
 def train_step_v1(model, optimizer, data, target):

@@ -611,6 +611,17 @@ class HipKernels:
                                                    out.numel(), _stream(dev)), 'relu_bwd')
         return dx
 
+    def scalar_sums(self, terms, n_a):
+        """-> 3 floats {sum of the first n_a single-element tensors, sum of the rest, both}: left-to-right fp32 adds in ONE launch
+        (deepipr_scalar_sums) instead of len(terms) one-element aten::add launches."""
+        dev = _chk(*terms)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        arr = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_scalar_sums(ctypes.addressof(arr), n_a, len(terms) - n_a, out.data_ptr(), _stream(dev)),
+                       'scalar_sums')
+        return out
+
     def sgd_momentum_step(self, flat_param, flat_grad, flat_buf, lr, momentum, weight_decay, grad_scale=1.0):
         """In-place SGD(momentum, weight decay) over flat fp32 buffers of equal length."""
         dev = _chk(flat_param, flat_grad, flat_buf)
@@ -1863,6 +1874,45 @@ class _CrossEntropyTop1(torch.autograd.Function):
             return None, None
         logits, target, lse = ctx.saved_tensors
         return kernels.ce_bwd(dloss.contiguous(), logits, target, lse), None
+
+
+class _ScalarSums(torch.autograd.Function):
+    """(a, b, a + b) with a / b the left-to-right sums of two groups of scalar tensors; backward hands every term the gradient
+    of the sums it is part of (no kernel when only a + b is differentiated: the usual case, the step's objective)."""
+
+    @staticmethod
+    def forward(ctx, n_a, *terms):
+        ctx.n_a, ctx.n = n_a, len(terms)
+        ctx.set_materialize_grads(False)
+        out = kernels.scalar_sums([t.detach().reshape(1) for t in terms], n_a)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, ga, gb, gt):
+        def both(x, y):
+            return y if x is None else (x if y is None else x + y)
+        da, db = both(ga, gt), both(gb, gt)
+        return (None,) + tuple(da if i < ctx.n_a else db for i in range(ctx.n))
+
+
+def scalar_sums(a_terms, b_terms):
+    """(sum(a_terms), sum(b_terms), their sum) of scalar tensors, summed left to right like the reference's loops
+    (`loss_public + loss_private`, `sign_loss += m.loss`, `loss + sign_loss`: experiments/trainer.py:140-145,
+    trainer_private.py:163-173).  CUDA fp32 scalars: one launch; anything else (host tensors in the CPU tests of the host logic):
+    the same chain of torch adds."""
+    terms = list(a_terms) + list(b_terms)
+    if (len(terms) >= 2 and len(terms) <= 48
+            and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms)):
+        a, b, tot = _ScalarSums.apply(len(a_terms), *terms)
+        return (a if a_terms else None), (b if b_terms else None), tot
+
+    def chain(ts):
+        total = None
+        for t in ts:
+            total = t if total is None else total + t
+        return total
+    a, b = chain(a_terms), chain(b_terms)
+    return a, b, (a if b is None else (b if a is None else a + b))
 
 
 def cross_entropy_top1(pred, target):

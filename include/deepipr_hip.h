@@ -410,6 +410,13 @@ int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int
 int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,
                    float *dlogits, void *stream);
 
+/* The scalar bookkeeping of a train step in one launch (ABI v10): out[0] = terms[0] + ... + terms[n_a-1], out[1] = the sum of the
+ * next n_b terms (both left to right -- the chain of one-element aten::add launches it replaces, bit for bit), out[2] = out[0] +
+ * out[1].  terms: HOST array of n_a + n_b (<= 48) device pointers to single floats (copied into the kernel arguments).
+ * replaces: `loss = ce (+ ce_private)`, `sign_loss += m.loss` over the SignLoss modules, `(loss + sign_loss).backward()`
+ *           (experiments/trainer.py:140-145, experiments/trainer_private.py:163-173). */
+int deepipr_scalar_sums(const float *const *terms, int n_a, int n_b, float *out, void *stream);
+
 /* ------------------------------------------------------------------ residual tail of a block
  * out = relu(a + b) in one pass (12 B/element), and its backward d = dy * [out > 0] (the same gradient goes
  * to both inputs).  All pointers 16-byte aligned, n floats.

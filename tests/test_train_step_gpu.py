@@ -252,3 +252,32 @@ def test_graphed_test_loop_equals_the_eager_one(K, private):
         layer.set_key(torch.randn_like(key), torch.randn_like(key))                    # a new key: new pooled means
         same()
         assert all(g.captures == 4 for g in counters)
+
+
+# ----------------------------------------------------------------------------- the step's scalar sums in one launch
+def test_scalar_sums_equal_the_chain_of_adds_bit_for_bit(K):
+    """deepipr_scalar_sums: `loss_public + loss_private`, `sign_loss += m.loss` over the layers and `loss + sign_loss`
+    (experiments/trainer.py:140-145, trainer_private.py:163-173) as ONE launch -- the same left-to-right fp32 adds, so the
+    same bits; the gradient of the objective reaches every term as 1."""
+    from deepipr_amd.passport_ops import scalar_sums
+    g = torch.Generator().manual_seed(11)
+    for n_a, n_b in [(1, 5), (2, 10), (1, 1), (2, 0), (0, 3), (1, 47)]:
+        vals = (torch.randn(n_a + n_b, generator=g) * torch.logspace(-3, 3, n_a + n_b)).to(DEV)
+        terms = [vals[i].clone().requires_grad_(True) for i in range(n_a + n_b)]        # 0-d tensors, like the losses
+        a, b, tot = scalar_sums(terms[:n_a], terms[n_a:])
+        ra = rb = None
+        for t in terms[:n_a]:
+            ra = t.detach() if ra is None else ra + t.detach()
+        for t in terms[n_a:]:
+            rb = t.detach() if rb is None else rb + t.detach()
+        want = ra if rb is None else (rb if ra is None else ra + rb)
+        assert (a is None) == (ra is None) and (b is None) == (rb is None)
+        assert (a is None or torch.equal(a.detach(), ra)) and (b is None or torch.equal(b.detach(), rb))
+        assert torch.equal(tot.detach(), want)
+        (tot * 3.0).backward()
+        assert all(float(t.grad) == 3.0 for t in terms)
+    # a term that is itself the output of an op keeps its place in the autograd graph
+    x = torch.tensor(2.0, device=DEV, requires_grad=True)
+    _a, _b, tot = scalar_sums([x * x], [x * 3.0, x.detach() * 0.5])
+    tot.backward()
+    assert float(x.grad) == 7.0 and float(tot) == 11.0
