@@ -18,7 +18,8 @@ def main():
     n = int(os.environ.get('WHATIF_BATCH', '128'))
     dev = torch.device('cuda:0')
     rec = {'mask': int(os.environ.get('WHATIF_MASK', '0')), 'N': n}
-    for c, hw in [(64, 32), (128, 16), (256, 8), (512, 4)]:
+    shapes = [(64, 56), (128, 28), (256, 14), (512, 7)] if os.environ.get('WHATIF_IMAGENET') == '1' else [(64, 32), (128, 16), (256, 8), (512, 4)]
+    for c, hw in shapes:
         x = torch.randn(n, c, hw, hw, device=dev)
         w = torch.randn(c, c, 3, 3, device=dev) * 0.05
         dy = torch.randn(n, c, hw, hw, device=dev)
