@@ -988,8 +988,8 @@ OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0' and OWN_CONV != '0'
 WINO_PRE = os.environ.get('DEEPIPR_WINO_PRE', '1') != '0' and OWN_CONV != '0'
 WINO_PRE_MAX_FILTERS = int(os.environ.get('DEEPIPR_WINO_PRE_MAX_FILTERS', 1 << 30))
 # ... and from this batch size up: the one transform launch per step (138 MB written for ResNet18) is paid back by the 26
-# convolution launches only when they are long enough (measured, bench.py replay: config R 128 images -0.6 %, V3 66 + 66
-# stacked -4.4 %, AlexNet 64 -1 %; config-P shard 32 images +0.9 %: off)
+# convolution launches only when they are long enough (measured, bench.py replay: config R 128 images -1.5 %, V3 66 + 66
+# stacked -9.6 %, AlexNet 64 -4.6 %; config-P shard 32 images +1.6 %: off)
 WINO_PRE_MIN_BATCH = int(os.environ.get('DEEPIPR_WINO_PRE_MIN_BATCH', 48))
 
 
@@ -1882,7 +1882,7 @@ class _ScalarSums(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n_a, *terms):
-        ctx.n_a, ctx.n = n_a, len(terms)
+        ctx.n_a, ctx.n, ctx.shapes = n_a, len(terms), [t.shape for t in terms]
         ctx.set_materialize_grads(False)
         out = kernels.scalar_sums([t.detach().reshape(1) for t in terms], n_a)
         return out[0], out[1], out[2]
@@ -1892,7 +1892,10 @@ class _ScalarSums(torch.autograd.Function):
         def both(x, y):
             return y if x is None else (x if y is None else x + y)
         da, db = both(ga, gt), both(gb, gt)
-        return (None,) + tuple(da if i < ctx.n_a else db for i in range(ctx.n))
+
+        def shaped(g, shape):                            # (a loss kept as a one-element vector gets its gradient in that shape)
+            return None if g is None else g.reshape(shape)
+        return (None,) + tuple(shaped(da if i < ctx.n_a else db, ctx.shapes[i]) for i in range(ctx.n))
 
 
 def scalar_sums(a_terms, b_terms):

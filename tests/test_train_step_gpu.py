@@ -281,3 +281,7 @@ def test_scalar_sums_equal_the_chain_of_adds_bit_for_bit(K):
     _a, _b, tot = scalar_sums([x * x], [x * 3.0, x.detach() * 0.5])
     tot.backward()
     assert float(x.grad) == 7.0 and float(tot) == 11.0
+    v = torch.ones(1, device=DEV, requires_grad=True)                                  # a one-element vector among the scalars
+    _a, _b, tot = scalar_sums([v * 2.0], [x.detach()])
+    tot.backward()
+    assert v.grad.shape == (1,) and float(v.grad) == 2.0
