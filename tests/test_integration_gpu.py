@@ -109,3 +109,31 @@ def test_section_c_convolution_stub_runs_on_the_gpu():
         for name, a, ref in (('y', y.detach(), y64.detach()), ('dx', x.grad, x64.grad), ('dW', w.grad, w64.grad)):
             err = float((a.double() - ref).abs().max()) / max(1e-12, float(ref.abs().max()))
             assert err <= 1e-5, (ci, co, h, k, st, name, err)
+
+
+def test_pre_transformed_winograd_stub_of_integration_md_runs_on_the_gpu():
+    """INTEGRATION.md section D, extracted and executed: the filter images written once, forward and backward-data from them --
+    bit-identical to the product's binding (same kernels) and within 2e-5 of scale of float64 ATen, small-batch deep layer
+    (split K over workgroups: the workspace path) included."""
+    from deepipr_amd import _lib
+    from deepipr_amd.passport_ops import kernels as K
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    code = next(b for b in blocks if b.lstrip().startswith('# models/layers/_deepipr_wino.py'))
+    ns = {}
+    exec(compile(code.replace('/path/to/libdeepipr_hip.so', _lib.LIB_PATH), 'INTEGRATION.md#D', 'exec'), ns)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    for n, ci, co, hw in [(16, 64, 64, 32), (8, 512, 512, 4), (5, 96, 64, 14)]:
+        x = torch.randn(n, ci, hw, hw, generator=g).to(dev)
+        w = (0.05 * torch.randn(co, ci, 3, 3, generator=g)).to(dev)
+        dy = torch.randn(n, co, hw, hw, generator=g).to(dev)
+        images = ns['winograd_images']([w])[0]
+        y = ns['conv3x3_pre'](x, w.shape, images)
+        dx = ns['conv3x3_pre'](x, w.shape, images, dy=dy)
+        assert torch.equal(y, K.conv_fwd(x, w, 1, 1)) and torch.equal(dx, K.conv_dgrad(dy, w, x.shape, 1, 1))
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [True, False, False])[0]
+        assert float((dx.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
