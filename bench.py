@@ -142,7 +142,7 @@ def fused_layer_elements(model, run_once):
 
 # The other BASELINE.json configurations that fit one GPU, measured in the SAME driver run as the headline (N = 1 only; a
 # bounded sub-run each, about 20 s with its find phase): one rank's shard of config 3 (V2, 100 classes, 32 images), config 4's
-# shard (V3: 64 images + the trigger pair) and config 1 (AlexNet V1, batch 64) on the GPU.
+# shard (V3: 64 images + the trigger pair), config 1 (AlexNet V1, batch 64) on the GPU and config 5's geometry (ResNet50, 40 s).
 OTHER_CONFIGS = [
     ('P_shard', 'BASELINE configs[2], one rank of 8: ResNet18 V2 private, CIFAR100 shapes, 32 images per GPU',
      ['--scheme', '2', '--classes', '100', '--batch', '32']),
@@ -150,6 +150,10 @@ OTHER_CONFIGS = [
      ['--scheme', '3', '--classes', '100', '--batch', '64']),
     ('AlexNet_A', 'BASELINE configs[0] on the GPU: AlexNet V1 passport, CIFAR10 shapes, batch 64',
      ['--arch', 'alexnet', '--batch', '64']),
+    # config 5 (ImageNet geometry; the ResNet50 passport variant is composed, the reference has none): a SHORT sub-run -- 8 timed
+    # steps of ~90 ms, MIOpen's immediate mode instead of its find phase (minutes for this net's shapes), no per-kernel timing
+    ('R50_imagenet', 'BASELINE configs[4] geometry, one rank: ResNet50 passport variant, 3x224x224, 1000 classes, 256 images per GPU',
+     ['--arch', 'resnet50', '--image-size', '224', '--classes', '1000', '--batch', '256', '--no-miopen-find', '--no-kernel-timing'], 8, 3),
 ]
 
 
@@ -161,8 +165,9 @@ def is_headline(args):
 def other_configs(steps=60, warmup=15, timeout=150):
     import subprocess
     res = {}
-    for key, what, flags in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline',
+    for key, what, flags, *own in OTHER_CONFIGS:
+        k_steps, k_warmup = own if own else (steps, warmup)
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(k_steps), '--warmup', str(k_warmup), '--no-cpu-baseline',
                '--no-stress', '--no-configs'] + flags
         t0 = time.perf_counter()
         try:
