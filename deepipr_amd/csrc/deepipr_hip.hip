@@ -4114,6 +4114,7 @@ int conv_algo() {
 
 #include "deepipr_conv.inc"
 #include "deepipr_conv_fwd.inc"
+#include "deepipr_conv_1x1.inc"
 
 template <class C>
 void launch_wgrad(ProfScope &prof, const WgradPlan &p, const float *x, const float *dy, float *part, int Ci, int Co, int H,
@@ -4174,9 +4175,30 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
                        p.splits);
         return check_launch("conv_wgrad");
     }
-    if (p.cfg >= 5000) {                                               // Winograd F(3x3, 2x2)
+    if (p.cfg >= 6000) {                                               // 1x1 stride 1 (deepipr_conv_1x1.inc)
+        ProfScope prof(DEEPIPR_K_CONV1X1_WGRAD, st);
+        prof.bytes = 2.0 * Co * Ci * static_cast<double>(N) * H * W;    // FLOPs
+        const int g1 = p.splits * p.wg_tiles_co * p.wg_tiles_ci;
+#define DEEPIPR_G1(BM, BN, HWP, NI, VEC)                                                                              \
+    DEEPIPR_LAUNCH(prof, (k_conv1x1_wgrad<G1Cfg<BM, BN, HWP, NI, VEC>>), dim3(g1), dim3(512), st, x, dy, part, N, Ci, Co, \
+                   H * W, p.wg_tiles_co, p.wg_tiles_ci, p.chunks, p.chunks_per_split)
+#define DEEPIPR_G1_GEO(CODE, HWP, NI, VEC)                                                                            \
+    case CODE + 11: DEEPIPR_G1(1, 1, HWP, NI, VEC); break;                                                            \
+    case CODE + 12: DEEPIPR_G1(1, 2, HWP, NI, VEC); break;                                                            \
+    case CODE + 21: DEEPIPR_G1(2, 1, HWP, NI, VEC); break;                                                            \
+    case CODE + 22: DEEPIPR_G1(2, 2, HWP, NI, VEC); break;
+        switch (p.cfg) {
+            DEEPIPR_G1_GEO(6100, 64, 1, 4)
+            DEEPIPR_G1_GEO(6200, 56, 1, 4)
+            DEEPIPR_G1_GEO(6300, 28, 2, 4)
+            DEEPIPR_G1_GEO(6400, 49, 1, 1)
+            default: return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no instance");
+        }
+#undef DEEPIPR_G1_GEO
+#undef DEEPIPR_G1
+    } else if (p.cfg >= 5000) {                                        // Winograd F(3x3, 2x2)
         ProfScope prof(DEEPIPR_K_CONV_WINO_WGRAD, st);
-        prof.bytes = 2.0 * Co * Ci * 16.0 * static_cast<double>(N) * (H / 2) * (W / 2);          // EXECUTED FLOPs (direct: x 2.25)
+        prof.bytes = 2.0 * Co * Ci * 16.0 * static_cast<double>(N) * ((H + 1) / 2) * ((W + 1) / 2);          // EXECUTED FLOPs (direct: x 2.25)
         const bool timed = prof.a && !prof.used;
         if (!dipr_launch_wgrad_wino(p.cfg - 5000, x, dy, part, N, Ci, Co, H, p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split,
                                     grid, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))

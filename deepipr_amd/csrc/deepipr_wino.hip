@@ -68,9 +68,26 @@ bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *p
         case 16: DIPR_WW(16, 2, 1);
         case 8: DIPR_WW(8, 4, 1);
         case 4: DIPR_WW(4, 2, 4);
-        default: return false;
+        default: break;
     }
 #undef DIPR_WW
+    // ImageNet-geometry maps: WxCfg<W, dy row width in LDS, tiles per (segment) row, tile rows, images, segments, floats per item>
+#define DIPR_WX(...)                                                                                                  \
+    do {                                                                                                              \
+        if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad_x<WxCfg<__VA_ARGS__>>), dim3(grid), dim3(256), 0, st, a, b, 0, x, dy, part, N, \
+                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split);                        \
+        else hipLaunchKernelGGL((k_conv_wino_wgrad_x<WxCfg<__VA_ARGS__>>), dim3(grid), dim3(256), 0, st, x, dy, part, N, Ci, Co, H,   \
+                                tiles_co, tiles_ci, chunks, chunks_per_split);                                        \
+        return true;                                                                                                  \
+    } while (0)
+    switch (width) {
+        case 56: DIPR_WX(56, 28, 14, 1, 1, 2, 4);
+        case 28: DIPR_WX(28, 28, 14, 1, 1, 1, 4);
+        case 14: DIPR_WX(14, 16, 8, 1, 2, 1, 2);
+        case 7: DIPR_WX(7, 8, 4, 4, 1, 1, 1);
+        default: return false;
+    }
+#undef DIPR_WX
 }
 
 FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride, int pad) {

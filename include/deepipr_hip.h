@@ -89,7 +89,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_WINO_DGRAD 28
 #define DEEPIPR_K_CONV_WINO_WGRAD 29     /* Winograd F(3x3, 2x2) weight gradient: EXECUTED FLOPs */
 #define DEEPIPR_K_CONV_WINO_WEIGHTS 30   /* the Winograd weight transform of the pre-transformed form (bytes: 36 in + 66 out per filter and direction) */
-#define DEEPIPR_PROFILE_KERNELS 31
+#define DEEPIPR_K_CONV1X1_WGRAD 31       /* 1x1 stride-1 weight gradient (deepipr_conv_1x1.inc): FLOPs */
+#define DEEPIPR_PROFILE_KERNELS 32
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */

@@ -55,6 +55,16 @@ SHAPES = [
     (128, 64, 128, 32, 32, 2, 1), (3, 64, 64, 32, 32, 2, 1), (128, 128, 256, 16, 16, 2, 1), (5, 128, 64, 16, 16, 2, 1),
     (128, 256, 512, 8, 8, 2, 1), (2, 256, 64, 8, 8, 2, 1), (32, 256, 512, 8, 8, 2, 1),
     # (the Winograd instances also take Ci a multiple of 32 and any batch on 4-wide maps: test_winograd_only_shapes)
+    # 1x1 stride 1 pad 0 (the Bottleneck's convbnrelu_1 / convbn_3 / stride-1 projection, BASELINE config 5;
+    # deepipr_conv_1x1.inc): every chunk geometry (64 | 56 | 2 x 28 positions, the 49-position plane with 4-byte loads),
+    # every workgroup tile (64 / 128 channels either side), odd batches on the two-image chunks, ragged last splits
+    (4, 64, 64, 56, 56, 1, 1), (3, 64, 256, 56, 56, 1, 1), (2, 256, 64, 56, 56, 1, 1), (2, 256, 128, 56, 56, 1, 1),
+    (32, 256, 64, 56, 56, 1, 1),
+    (5, 128, 512, 28, 28, 1, 1), (3, 192, 64, 28, 28, 1, 1), (2, 64, 128, 28, 28, 1, 1), (3, 512, 128, 28, 28, 1, 1),
+    (5, 256, 1024, 14, 14, 1, 1), (4, 1024, 256, 14, 14, 1, 1), (1, 64, 128, 14, 14, 1, 1), (7, 128, 64, 14, 14, 1, 1),
+    (7, 512, 2048, 7, 7, 1, 1), (3, 2048, 512, 7, 7, 1, 1), (2, 64, 64, 7, 7, 1, 1), (5, 64, 128, 7, 7, 1, 1),
+    (2, 128, 64, 7, 7, 1, 1), (256, 512, 2048, 7, 7, 1, 1), (64, 1024, 256, 14, 14, 1, 1),
+    (2, 64, 64, 8, 8, 1, 1), (3, 128, 128, 16, 4, 1, 1),
     # the stem: 3 input channels, (ci, tap) = 27 columns of one accumulator tile
     (128, 3, 64, 32, 32), (5, 3, 64, 32, 32), (32, 3, 128, 32, 32), (2, 3, 64, 8, 32),
 ]
@@ -143,10 +153,17 @@ def test_bf16x3_split_is_exact_for_every_fp32_value(K):
 
 
 @pytest.mark.parametrize('shape', [(3, 64, 64, 4, 4), (66, 512, 512, 4, 4), (7, 32, 64, 8, 8), (5, 96, 128, 16, 16), (2, 160, 64, 2, 32),
-                                   (132, 512, 512, 4, 4), (9, 32, 192, 12, 4)], ids=lambda s: 'x'.join(map(str, s)))
+                                   (132, 512, 512, 4, 4), (9, 32, 192, 12, 4),
+                                   # ImageNet-geometry maps (BASELINE config 5; k_conv_wino_wgrad_x): two column segments per
+                                   # 56-wide row, 8-byte items and two-image chunks on 14-wide maps (odd batches masked), 4-byte
+                                   # items and half-phantom tiles on 7 x 7 maps; non-square maps; ragged last splits
+                                   (3, 64, 64, 56, 56), (2, 32, 128, 56, 56), (2, 64, 64, 6, 56), (16, 64, 64, 56, 56),
+                                   (5, 128, 128, 28, 28), (3, 64, 192, 28, 28), (2, 32, 64, 20, 28),
+                                   (5, 256, 256, 14, 14), (4, 32, 64, 14, 14), (3, 64, 64, 6, 14), (64, 256, 256, 14, 14),
+                                   (7, 512, 512, 7, 7), (3, 96, 64, 7, 7), (256, 512, 512, 7, 7)], ids=lambda s: 'x'.join(map(str, s)))
 def test_winograd_only_shapes(K, shape):
-    """Shapes only the Winograd F(3x3, 2x2) instance takes: ragged image groups on 4-wide maps (any N: V3's 66 images, the
-    stacked branches' 132), Ci a multiple of 32."""
+    """Shapes only the Winograd F(3x3, 2x2) instances take: ragged image groups on 4-wide maps (any N: V3's 66 images, the
+    stacked branches' 132), Ci a multiple of 32, the ImageNet-geometry map widths 56 / 28 / 14 / 7."""
     if K.conv_algo() != 'winograd':
         pytest.skip('the Winograd instances')
     n, ci, co, h, w = shape
@@ -162,7 +179,7 @@ def test_one_hot_small_integers_are_exact_in_the_winograd_kernel(K):
     """Small-integer operands on every map width: the transforms only add (and halve at the very end), so every dW entry is
     exact -- a wrong tap, a halo that is not zero, a tile pair read from the wrong place or a sign folded the wrong way is an
     exact mismatch.  (Runs in every mode: the direct kernels are exact here too.)"""
-    for hw in (4, 8, 16, 32):
+    for hw in (4, 8, 16, 32, 56, 28, 14, 7):
         n, ci, co = 5, 32, 64
         rs = np.random.RandomState(hw)
         x = torch.zeros(n, ci, hw, hw, device=DEV)
@@ -175,6 +192,34 @@ def test_one_hot_small_integers_are_exact_in_the_winograd_kernel(K):
             continue
         ref = _ref(x, dy, (co, ci, 3, 3))
         assert float(ref.abs().sum()) > 0 and torch.equal(got.double(), ref), hw
+
+
+def test_1x1_stride1_one_hot_small_integers_are_exact(K):
+    """Small integers at sparse positions, every chunk geometry of the 1x1 stride-1 kernel: each dW entry is an exact
+    small sum -- a position read from the wrong plane, a pad that is not zero, a group pair skipped or taken twice, or a
+    32 x 32 block written to the wrong slot of the partial tiles is an exact mismatch."""
+    for hw, n, ci, co in ((56, 3, 128, 64), (28, 3, 64, 192), (14, 5, 128, 128), (7, 4, 192, 128)):
+        rs = np.random.RandomState(hw)
+        x = torch.zeros(n, ci, hw, hw, device=DEV)
+        dy = torch.zeros(n, co, hw, hw, device=DEV)
+        for _ in range(3000):
+            i, j = rs.choice([0, hw - 1, rs.randint(hw)]), rs.choice([0, hw - 1, rs.randint(hw)])
+            x[rs.randint(n), rs.randint(ci), i, j] = float(rs.randint(1, 5))
+            dy[rs.randint(n), rs.randint(co), i, j] = float(rs.randint(1, 4))
+        got = K.conv_wgrad(x, dy, (co, ci, 1, 1), 1, 0)
+        assert got is not None
+        ref = _ref(x, dy, (co, ci, 1, 1), 1, 0)
+        assert float(ref.abs().sum()) > 0 and torch.equal(got.double(), ref), hw
+
+
+def test_rank2_term_fused_into_the_1x1_stride1_reduction_equals_the_separate_update(K):
+    n, ci, co, h = 6, 512, 256, 7
+    x, dy = _rand((n, ci, h, h), 5), _rand((n, co, h, h), 6)
+    dg, db = _rand((co,), 7), _rand((co,), 8)
+    m = torch.rand(2, ci, dtype=torch.float64, device=DEV) * 2 - 1
+    fused = K.conv_wgrad(x, dy, (co, ci, 1, 1), 1, 0, dg, db, m)
+    plain = K.conv_wgrad(x, dy, (co, ci, 1, 1), 1, 0)
+    assert torch.equal(fused, K.gamma_beta_bwd_acc(dg, db, m, plain.clone()))
 
 
 def test_rank2_term_fused_into_the_1x1_reduction_equals_the_separate_update(K):
@@ -200,8 +245,8 @@ def test_rank2_term_fused_into_the_reduction_equals_the_separate_update(K):
 
 
 @pytest.mark.parametrize('case', [
-    dict(n=4, ci=3, co=64, h=16, w=16), dict(n=4, ci=4, co=64, h=32, w=32), dict(n=4, ci=64, co=64, h=14, w=14), dict(n=4, ci=64, co=96, h=8, w=8),
-    dict(n=4, ci=64, co=64, h=8, w=8, k=1, pad=0), dict(n=4, ci=64, co=64, h=64, w=64, stride=2),
+    dict(n=4, ci=3, co=64, h=16, w=16), dict(n=4, ci=4, co=64, h=32, w=32), dict(n=4, ci=64, co=64, h=10, w=10), dict(n=4, ci=64, co=64, h=8, w=7), dict(n=4, ci=64, co=96, h=8, w=8),
+    dict(n=4, ci=64, co=64, h=5, w=5, k=1, pad=0), dict(n=4, ci=32, co=64, h=8, w=8, k=1, pad=0), dict(n=4, ci=64, co=64, h=64, w=64, stride=2),
     dict(n=4, ci=64, co=64, h=8, w=8, stride=3),
     dict(n=3, ci=64, co=64, h=4, w=4)])
 def test_shapes_outside_the_kernel_are_refused_before_anything_is_enqueued(K, case):
