@@ -88,10 +88,12 @@ def _leave():
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() > 1:
         sys.stdout.flush()
         sys.stderr.flush()
+        code = 0
         try:
             D.barrier()
-        except Exception as e:                               # a peer is gone: say so, leave anyway
+        except Exception as e:                               # a peer is gone: say so, leave anyway -- with a non-zero exit code
             print('bench.py: final barrier failed: %s' % e, file=sys.stderr, flush=True)
+            code = 3
         if os.environ.get('DEEPIPR_BENCH_HARD_EXIT', '1') != '0':
             import atexit
             try:
@@ -99,7 +101,9 @@ def _leave():
             finally:
                 sys.stdout.flush()
                 sys.stderr.flush()
-                os._exit(0)
+                os._exit(code)
+        if code:
+            sys.exit(code)
     D.shutdown()
 
 
@@ -275,6 +279,21 @@ def stress_roofline(device, reps=30):
     return {'bound': 'hbm', 'kernel': 'k_' + dom, 'shape': [n, c, h, w], 'achieved': a['GBps'],
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(a['GBps'] / HBM_PEAK_GBS, 4),
             'bytes_per_launch': a['bytes_per_launch'], 'avg_us': a['avg_us'], 'kernels': res}
+
+
+def pmc_record_stale(kernel, shape_key):
+    """The committed PMC record names the kernel source it was measured on (`source`, `source_sha16`): True when that file has
+    changed since (the record is then a figure about an OLDER kernel and is printed flagged), None when the record carries no
+    such stamp."""
+    import hashlib
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))[kernel][shape_key]
+        if 'source_sha16' not in rec:
+            return None
+        now = hashlib.sha256(open(os.path.join(ROOT, rec['source']), 'rb').read()).hexdigest()[:16]
+        return now != rec['source_sha16']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel, shape_key, algorithmic=None):
@@ -614,6 +633,22 @@ def main():
     D.barrier()
     dt = time.perf_counter() - t0
     note('timed region done: %.3f ms per step' % (1000.0 * dt / args.steps))
+    # `value` is EXACTLY the --steps region above (the driver's contract).  A short one (the driver's 20 steps of 3.5 ms are 0.07 s)
+    # is backed by a second, longer region of the same step right after it -- reported beside it, never instead of it
+    # (VERDICT r05 weak 8): at least 100 steps, bounded to about two seconds.
+    steady = None
+    if args.steps < 100 and dt > 0:
+        ks = int(min(max(100, args.steps), max(args.steps, 2.0 / (dt / args.steps))))
+        if ks > args.steps:
+            D.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(ks):
+                step(i)
+            torch.cuda.synchronize()
+            D.barrier()
+            steady = {'steps': ks, 'ms_per_step': round(1000.0 * D.max_over_ranks(time.perf_counter() - t1, device) / ks, 4)}
+            note('steady-state check: %d steps, %.3f ms per step' % (ks, steady['ms_per_step']))
     sampled = len(range(0, args.steps, stride))
     _k.profile_passport = timing                           # passport-layer launches also go to the scoped counters
     if timing and use_graph:
@@ -667,6 +702,7 @@ def main():
         'value': round(value, 1), 'unit': 'img/s',
         'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'steady_state_check': steady,                      # a longer region of the same step behind a short --steps (None otherwise)
         'vs_baseline': None, 'dtype': 'f32' if _conv_arith() != 'bf16x3' else 'f32 (3x3 stride-1 weight gradients: bf16x3 products, f32 accumulate)',
         'data': 'synthetic',
         'sign_detect_acc': round(sum(detect.values()) / max(1, len(detect)), 4),
@@ -674,6 +710,7 @@ def main():
         'exchange_timeouts': _exchange_timeouts(),
         'world_size_seen': (_td.get_world_size() if tdist_on else 1),
         'rccl_ranks_seen': ranks_seen,                     # measured by a collective, not read from the environment
+        'ranks_seen_backend': (_td.get_backend() if tdist_on else None),      # what counted them: 'nccl' (= RCCL) | 'gloo' | None (no process group)
         # after the find phase every rank ran the same forward + backward (rank 0's batch, broadcast weights): identical
         # gradients bit for bit / within 1e-5 of scale (None on one GPU)
         'ranks_agree_bitwise': agree, 'ranks_agree_1e-5': agree_tol, 'ranks_agree_detail': agree_detail, 'same_rank_repeat_agrees': repeat,
@@ -817,12 +854,10 @@ def main():
                 # this configuration, profiles/pmc_traffic.json, round 5; Infinity-Cache hits are counted by these counters)
                 fam = 'k_conv_wino_wgrad' if slot == 'conv_wino_wgrad' else 'k_conv_wino'
                 rec['traffic'] = pmc_traffic(fam, 'in_situ_per_launch')
-                rec['traffic_source'] = 'profiles/pmc_traffic.json: %s (round-5 record, average over the family\'s launches of the step)' % fam
-            if slot == 'conv_wgrad' and args.arch == 'resnet18' and args.batch == 128 and args.image_size == 32 and False:
-                # HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over the eager step,
-                # profiles/pmc_traffic.json), recorded when this slot still held all 16 3x3 launches
-                rec['traffic'] = pmc_traffic('k_conv3x3_wgrad', 'in_situ_per_launch')
-                rec['traffic_source'] = 'profiles/pmc_traffic.json: k_conv3x3_wgrad (fp32-MFMA instances, round-4 record)'
+                # the record is a committed measurement, not one of this run: it names the kernel source it was taken on, and a
+                # source that has changed since is said so
+                rec['traffic_stale'] = pmc_record_stale(fam, 'in_situ_per_launch')
+                rec['traffic_source'] = 'profiles/pmc_traffic.json: %s (committed record, average over the family\'s launches of the step)' % fam
             mfma_all[slot] = rec
         if mfma_all:
             mfma = max(mfma_all.values(), key=lambda r: r['us_per_step'])

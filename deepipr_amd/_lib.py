@@ -60,6 +60,10 @@ SIGNATURES = {
     'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd2': (_int, [_f32p, _f32p, _f32p, _f32p, _sz, _vp]),
+    'deepipr_subsample2': (_int, [_f32p, _f32p, _sz, _int, _int, _vp]),
+    'deepipr_upsample2_zero': (_int, [_f32p, _f32p, _sz, _int, _int, _vp]),
+    'deepipr_maxpool3x3s2_fwd': (_int, [_f32p, _f32p, _vp, _sz, _int, _int, _vp]),
+    'deepipr_maxpool3x3s2_bwd': (_int, [_f32p, _vp, _f32p, _sz, _int, _int, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
     'deepipr_sgd_momentum_chunk': (_int, []),
@@ -117,9 +121,9 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_debug_wino_trace': (_int, [_vp]),
 }
-ABI_VERSION = 10
-SYNC_WORDS = 2 * (256 * 30 * 4 + 2048) + 16     # DEEPIPR_SYNC_WORDS
-SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
+ABI_VERSION = 11
+SYNC_WORDS = 2 * (256 * 30 * 4 + 4096) + 16     # DEEPIPR_SYNC_WORDS
+SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 4096)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
 
 GEMV_MAX_LAYERS = 16                    # DEEPIPR_GEMV_MAX_LAYERS
@@ -189,7 +193,7 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum',
-                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad']
+                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad', 'maxpool', 'resample2']
 
 
 class ExternalEvent:

@@ -1496,11 +1496,12 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 // ============================================================================================
 // Exchange buffer (`sync`, DEEPIPR_SYNC_WORDS 32-bit words = granules of 8 bytes): for every slice count S in
 // {2, 4, 8, 16} a region of kXchChannels x S slots of 4 granules, for S in {32, 64} (maps too large for one pass, see
-// plan_resident) a region of 1024 granules each; then the time-out word.  A slot is addressed by the channel's index
-// WITHIN the launch (a launch splits at most 256 / S channels), so channel-range passes of one layer reuse the slots.
+// plan_resident) a region of 2048 granules each (two sets of 256 / S channel slots: the ranges kernels alternate between
+// them, ABI v11); then the time-out word.  A slot is addressed by the channel's index WITHIN the launch (a launch splits at
+// most 256 / S channels), so the channel ranges of one layer reuse the slots.
 constexpr int kXchChannels = 256;                  // channels are split only when C < CUs, i.e. C <= 255
 constexpr int kXchMaxSlices = 64;                  // 4 granules per slice: up to 256 granules, four per lane of wave 0
-constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4 + 2 * 1024;
+constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4 + 2 * 2048;      // S = 32 / 64: two slot sets of 256 / S channels each
 constexpr int kSyncTimeoutWord = 2 * kXchGranules;
 static_assert(kSyncTimeoutWord == DEEPIPR_SYNC_TIMEOUT_WORD && kSyncTimeoutWord + 16 == DEEPIPR_SYNC_WORDS, "header out of step");
 constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(2) + one poll: a few seconds
@@ -1512,6 +1513,7 @@ struct ResPlan {
     int blocks;           // workgroups of this launch: (channels of the pass / G) * S
     int c_off;            // first channel of this launch (channel-range passes of a map too large for one pass)
     int cpp, passes;      // host side: channels per pass, number of passes (1: the whole layer in one launch)
+    int stagger;          // ranges kernels: odd channel groups start this many s_sleep(127) late (phases of neighbours interleave)
     FastDiv gqdiv;
 #ifdef DEEPIPR_TEST_HOOKS
     // Measurement / test build only (`make trace`: libdeepipr_hip_trace.so; the production library has none of this):
@@ -1653,7 +1655,7 @@ __device__ __forceinline__ unsigned long long xch_load(const unsigned long long 
 
 __device__ __forceinline__ int xch_region(int S) {
     if (S <= 16) return kXchChannels * (S - 2) * 4;                         // 2 + 4 + ... + S/2 = S - 2
-    return kXchChannels * 30 * 4 + (S == 32 ? 0 : 1024);
+    return kXchChannels * 30 * 4 + (S == 32 ? 0 : 2048);
 }
 
 // Called by every thread at kernel entry (only wave 0 needs it; one L2 round trip hidden behind the bulk loads).
@@ -1766,27 +1768,30 @@ __device__ __forceinline__ void sign_loss_block_t(const float *__restrict__ gamm
     }
 }
 
-template <int T, int F4>
-__global__ __launch_bounds__(T) void k_bn_res_fwd(
+// All workgroups of a ranges launch are symmetric, so without help they stay in phase for the whole launch: the chip reads, then
+// exchanges (HBM idle), then writes.  The workgroups of every other channel start late by about half a range: their loads fall
+// into their neighbours' exchange and store phases for the rest of the launch.  (All S partners of a channel wait together.)
+__device__ __forceinline__ void res_stagger(const ResPlan &pl, int cb) {
+    if (cb & 1)
+        for (int i = 0; i < pl.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
+// One channel range of the forward kernel: workgroup (cb, s) takes channel(s) c_off + cb * G of its batch slice.  `xc`: the
+// exchange slots of this range (S > 1); first: the range that counts the call (num_batches_tracked).
+template <int T, int F4, bool LOOP = false>
+__device__ __forceinline__ void bn_res_fwd_range(
     const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
-    const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
-    unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
-    constexpr int NW = T / kWave;
-    __shared__ double red[2 * NW * 8];
-    __shared__ double xch[2];
-    if (with_sign && static_cast<int>(blockIdx.x) == pl.blocks) {
-        sign_loss_block_t<T>(gamma, sa, C, red);
-        return;
-    }
-    const int t = threadIdx.x;
-    int cb, s;
-    res_block_coords(pl, cb, s);
-    const int c0 = pl.c_off + cb * pl.G;
-    const int n0 = s * pl.nps;
+    const float *__restrict__ beta, int relu, int N, int C, const ResPlan &pl, const BnFinishArgs &f,
+    unsigned *sync, const float4 *__restrict__ residual, double *red, double *xch, int cb, int s, int c_off,
+    const ResXch &xc, bool first) {
+    int t = threadIdx.x;
+    int n0 = s * pl.nps;
+    // inside k_bn_res_fwd_ranges' loop: nothing derived from the thread index or the slice may be hoisted out of it (the
+    // unit -> address arithmetic is range-invariant: hipcc kept 2 * F4 values of it alive across the loop and spilled)
+    if (LOOP) asm volatile("" : "+v"(t), "+s"(n0));
+    const int c0 = c_off + cb * pl.G;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;        // T % gq == 0: the same for all of t's units
-    ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);              // slot = the channel's index within this launch
     // shift of the statistics (see BnFinishArgs): the channel's first element, identical in all S slices
     res_stamp(pl, 0);
     // what the channel table needs besides the sums, loaded up front
@@ -1801,14 +1806,14 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     const float K = reinterpret_cast<const float *>(x)[static_cast<size_t>(c0 + c_local) * pl.q4 * 4];
     // float4 index of unit j of this workgroup's slice; kept in registers for the write phase only while that is
     // affordable (F4 <= 8): the F4 = 12 / 16 instances sit at the 128-VGPR limit and recompute it instead
-    constexpr bool kKeepIdx = F4 <= 8;
+    constexpr bool kKeepIdx = F4 <= (LOOP ? 6 : 8);           // (the loop over ranges costs the 8-unit instance its last registers)
     auto unit_index = [&](int j) {
         const unsigned row = fdiv(static_cast<unsigned>(j), pl.gqdiv);
         return static_cast<unsigned>((static_cast<size_t>(n0 + row) * C + c0) * pl.q4 + (j - row * pl.gq));
     };
     // the shortcut of a folded residual tail is fetched in the SAME load phase (while registers allow): read after
     // the statistics it would be a second, latency-bound load phase in front of the stores
-    constexpr bool kPreRes = F4 <= 8;
+    constexpr bool kPreRes = F4 <= (LOOP ? 6 : 8);
     float4 v[F4];
     float4 rs[kPreRes ? F4 : 1];
     unsigned idx[kKeepIdx ? F4 : 1];
@@ -1870,7 +1875,7 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
         row[0] = ch;
         row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && t == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+    if (first && blockIdx.x == 0 && t == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
     res_stamp(pl, 3);
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
@@ -1895,6 +1900,52 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     res_stamp(pl, 4);
 }
 
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_fwd(
+    const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
+    const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, double *part,
+    unsigned *sync, int with_sign, SignArgs sa, const float4 *__restrict__ residual) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[2];
+    if (with_sign && static_cast<int>(blockIdx.x) == pl.blocks) {
+        sign_loss_block_t<T>(gamma, sa, C, red);
+        return;
+    }
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    ResXch xc{};
+    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);              // slot = the channel's index within this launch
+    bn_res_fwd_range<T, F4>(x, y, gamma, beta, relu, N, C, pl, f, sync, residual, red, xch, cb, s, pl.c_off, xc, true);
+}
+
+// Maps beyond the register file (ImageNet geometry): ALL channel ranges of the layer in ONE launch.  Round 5 launched the
+// kernel above once per range (ResNet50 at batch 256: 189 forward + 390 backward launches of ~30 us, each with its own ramp
+// and a read phase that cannot start before the previous launch's write phase has drained: 0.40 - 0.46 of the HBM peak).
+// Here workgroup (cb, s) walks the ranges cb, cb + cpp, cb + 2 cpp, ... itself; the workgroups drift apart, so one's stores
+// overlap another's loads.  The exchange alternates between two slot sets (channel indices cb and cb + cpp of the S-region: a
+// region has 256 slots, a range uses 256 / S): a workgroup may publish range r + 2 into the set of range r only after it has
+// finished range r + 1, which needs every partner's r + 1 granule, which a partner writes only after it has READ range r.
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_fwd_ranges(
+    const float4 *__restrict__ x, float4 *__restrict__ y, const float *__restrict__ gamma,
+    const float *__restrict__ beta, int relu, int N, int C, ResPlan pl, BnFinishArgs f, unsigned *sync,
+    const float4 *__restrict__ residual) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[2];
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    res_stagger(pl, cb);
+    for (int r = 0; r < pl.passes; ++r) {
+        const int c_off = r * pl.cpp;
+        if (cb * pl.G >= C - c_off) break;                             // the last range may be short (whole workgroups leave)
+        // this range's slot set; its tag is read afresh (this workgroup's own granule of range r - 2: old + 1 again)
+        const ResXch xc = res_xch_begin(sync, cb + (r & 1) * pl.cpp, s, pl.S);
+        bn_res_fwd_range<T, F4, true>(x, y, gamma, beta, relu, N, C, pl, f, sync, residual, red, xch, cb, s, c_off, xc, r == 0);
+    }
+}
+
 struct ResBwdArgs {
     const float *b;                 // signature bits (sign loss), may be nullptr
     float alpha, margin, l2;
@@ -1913,22 +1964,17 @@ __device__ __forceinline__ void res_bwd_prep(float d, float xv, const float4 &ch
     if (relu) dz = (__fadd_rn(__fmul_rn(ch.z, xh), ch.w) > 0.0f) ? d : 0.0f;
 }
 
-template <int T, int F4>
-__global__ __launch_bounds__(T) void k_bn_res_bwd(
+template <int T, int F4, bool LOOP = false>
+__device__ __forceinline__ void bn_res_bwd_range(
     const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
-    float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, double *part, unsigned *sync, ResBwdArgs a) {
-    constexpr int NW = T / kWave;
-    __shared__ double red[2 * NW * 8];
-    __shared__ double xch[2];
-    const int t = threadIdx.x;
-    int cb, s;
-    res_block_coords(pl, cb, s);
-    const int c0 = pl.c_off + cb * pl.G;
-    const int n0 = s * pl.nps;
+    float4 *__restrict__ dx, int relu, int N, int C, const ResPlan &pl, unsigned *sync, const ResBwdArgs &a,
+    double *red, double *xch, int cb, int s, int c_off, const ResXch &xc) {
+    int t = threadIdx.x;
+    int n0 = s * pl.nps;
+    if (LOOP) asm volatile("" : "+v"(t), "+s"(n0));           // (bn_res_fwd_range)
+    const int c0 = c_off + cb * pl.G;
     const int units = max(0, min(N, n0 + pl.nps) - n0) * pl.gq;
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
-    ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);
     res_stamp(pl, 0);
     const float4 ch = *reinterpret_cast<const float4 *>(tbl + static_cast<size_t>(c0 + c_local) * kTbl);
     float4 dz[F4], xh[F4];
@@ -2011,6 +2057,39 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
         }
     }
     res_stamp(pl, 4);
+}
+
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_bwd(
+    const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
+    float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, double *part, unsigned *sync, ResBwdArgs a) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[2];
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    ResXch xc{};
+    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);
+    bn_res_bwd_range<T, F4>(dy, x, tbl, dx, relu, N, C, pl, sync, a, red, xch, cb, s, pl.c_off, xc);
+}
+
+// all channel ranges of a map beyond the register file in one launch (k_bn_res_fwd_ranges)
+template <int T, int F4>
+__global__ __launch_bounds__(T) void k_bn_res_bwd_ranges(
+    const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ tbl,
+    float4 *__restrict__ dx, int relu, int N, int C, ResPlan pl, unsigned *sync, ResBwdArgs a) {
+    constexpr int NW = T / kWave;
+    __shared__ double red[2 * NW * 8];
+    __shared__ double xch[2];
+    int cb, s;
+    res_block_coords(pl, cb, s);
+    res_stagger(pl, cb);
+    for (int r = 0; r < pl.passes; ++r) {
+        const int c_off = r * pl.cpp;
+        if (cb * pl.G >= C - c_off) break;
+        const ResXch xc = res_xch_begin(sync, cb + (r & 1) * pl.cpp, s, pl.S);
+        bn_res_bwd_range<T, F4, true>(dy, x, tbl, dx, relu, N, C, pl, sync, a, red, xch, cb, s, c_off, xc);
+    }
 }
 
 // ============================================================================================
@@ -2945,7 +3024,7 @@ int deepipr_profile_enable(int on) {
 }
 
 namespace {
-void prof_drain_locked() {                         // everything recorded so far
+static void prof_drain_locked() {                  // everything recorded so far (static: this namespace sits inside extern "C")
     for (auto &p : g_prof.pending) {
         float ms = 0.0f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -3363,12 +3442,15 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         if (!can_sync || G != 1) return false;
         const int lim = cus < kXchChannels ? cus : kXchChannels;
         bool found = false;
+        // (at most 12 float4 per thread: the 16-unit forward instance has no register to spare for the loop over ranges of
+        // k_bn_res_fwd_ranges -- 24 spilled -- and a range is a loop iteration now, not a launch)
+        const int pass_f4 = max_f4 > 12 ? 12 : max_f4;
         for (int Sp = 2; Sp <= kXchMaxSlices && Sp <= N && Sp <= lim; Sp *= 2) {
             const long long nps = (N + Sp - 1) / Sp;
             const long long nd = (nps * pl.q4 + 1023) / 1024;
             int f4 = 0;
             for (int f : steps)
-                if (f >= nd && f <= max_f4) {
+                if (f >= nd && f <= pass_f4) {
                     f4 = f;
                     break;
                 }
@@ -3428,6 +3510,38 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
     return check_launch("passport_bn_fwd(resident)");
 }
 
+// late start of the odd channel groups in units of s_sleep(127) (~3.9 us at 2.1 GHz); DEEPIPR_BN_STAGGER="fwd,bwd" overrides
+int ranges_stagger(int backward) {
+    static int v[2] = {-1, -1};
+    if (v[0] < 0) {
+        v[0] = 0;
+        v[1] = 0;
+        if (const char *e = getenv("DEEPIPR_BN_STAGGER")) {
+            int a = 0, b = 0;
+            const int n = sscanf(e, "%d,%d", &a, &b);
+            if (n >= 1 && a >= 0 && a <= 64) v[0] = a;
+            v[1] = (n >= 2 && b >= 0 && b <= 64) ? b : v[0];
+        }
+    }
+    return v[backward];
+}
+
+// all `pl.passes` channel ranges of the layer in one launch (k_bn_res_fwd_ranges); false: no instance (the caller loops)
+bool launch_res_fwd_ranges(const float *x, float *y, const float *gamma, const float *beta, int relu, int N, int C,
+                           const ResPlan &pl, const BnFinishArgs &f, unsigned *sync, const float *residual, hipStream_t st) {
+    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp > kXchChannels || (pl.F4 != 12 && pl.F4 != 8)) return false;
+    ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
+    prof.bytes = (residual ? 12.0 : 8.0) * static_cast<double>(N) * C * pl.q4 * 4;
+    const dim3 grid(pl.cpp * pl.S);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *r4 = reinterpret_cast<const float4 *>(residual);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    ResPlan q = pl;
+    q.stagger = ranges_stagger(0);
+    if (pl.F4 == 12) DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
+    else DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 8>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
+    return true;
+}
+
 int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
                    const ResPlan &pl, double *part, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
     ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
@@ -3442,6 +3556,21 @@ int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx,
         DEEPIPR_RES_CASES(k_bn_res_bwd, 1024, d4, x4, tbl, o4, relu, N, C, pl, part, sync, a)
     }
     return check_launch("passport_bn_bwd(resident)");
+}
+
+bool launch_res_bwd_ranges(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
+                           const ResPlan &pl, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
+    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp > kXchChannels || (pl.F4 != 6 && pl.F4 != 8)) return false;
+    ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
+    prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : (a.dy2 ? 16.0 : 12.0)) * static_cast<double>(N) * C * pl.q4 * 4;
+    const dim3 grid(pl.cpp * pl.S);
+    const float4 *d4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *o4 = reinterpret_cast<float4 *>(dx);
+    ResPlan q = pl;
+    q.stagger = ranges_stagger(1);
+    if (pl.F4 == 6) DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 6>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
+    else DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 8>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
+    return true;
 }
 
 
@@ -3514,7 +3643,7 @@ namespace {
 // would take (same T, S, F4: that is what makes the dual form bit-identical to them).  Backward keeps three register
 // arrays per unit, so a 1024-thread workgroup is limited to 4 float4 per thread (a 256-thread one may use 8: one
 // wave per SIMD has the whole register file).
-bool plan_dual(int N, int C, int HW, bool can_sync, ResPlan *out) {
+static bool plan_dual(int N, int C, int HW, bool can_sync, ResPlan *out) {
     ResPlan rp;
     if (!plan_resident(N, C, HW, 8, can_sync, &rp) || rp.passes != 1) return false;
     if (rp.T == 1024 && rp.F4 > 4) return false;
@@ -3690,6 +3819,10 @@ int deepipr_passport_bn_fwd(const float *x, const float *W, const double *m, con
         f.part = part;
         f.NS = rp.S;
         SignArgs sa{b, alpha, margin, l2, loss, acc, bits};
+        static const bool one_launch = !(getenv("DEEPIPR_BN_RANGES") && !atoi(getenv("DEEPIPR_BN_RANGES")));      // A/B knob
+        if (one_launch && rp.passes > 1 && !with_sign &&
+            launch_res_fwd_ranges(x, y, g, bt, relu, N, C, rp, f, sync, residual, st))
+            return check_launch("passport_bn_fwd(resident, ranges)");
         for (int p = 0; p < rp.passes; ++p) {              // one launch, or channel-range passes of a large map
             ResPlan q = rp;
             q.c_off = p * rp.cpp;
@@ -3798,6 +3931,12 @@ int deepipr_passport_bn_bwd(const float *dy, const float *x, const float *table,
                      training ? 1.0 / (static_cast<double>(N) * HW) : 0.0,
                      reinterpret_cast<const float4 *>(dy2), reinterpret_cast<const float4 *>(tail_out),
                      reinterpret_cast<float4 *>(dres)};
+        static const bool one_launch = !(getenv("DEEPIPR_BN_RANGES") && !atoi(getenv("DEEPIPR_BN_RANGES")));
+        if (one_launch && rp.passes > 1 && launch_res_bwd_ranges(dy, x, table, dx, relu, N, C, rp, sync, a, st)) {
+            const int rc = check_launch("passport_bn_bwd(resident, ranges)");
+            if (rc != DEEPIPR_OK) return rc;
+            return dW ? deepipr_gamma_beta_bwd(dgamma, dbeta, m, C, K, dW, stream) : DEEPIPR_OK;
+        }
         for (int p = 0; p < rp.passes; ++p) {
             ResPlan q = rp;
             q.c_off = p * rp.cpp;
@@ -4093,6 +4232,261 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
     if (dy2) DEEPIPR_LAUNCH(prof, k_relu_bwd<true>, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, dy, dy2, out, dx, n);
     else DEEPIPR_LAUNCH(prof, k_relu_bwd<false>, dim3(grid_for((n + 3) / 4)), dim3(kThreads), st, dy, dy2, out, dx, n);
     return check_launch("relu_bwd");
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// 3x3 stride-2 pad-1 max-pool of the ImageNet stem (models/resnet_passport.py:94-98: nn.MaxPool2d(3, 2, 1) behind the 7x7
+// convolution) -- HBM-bound.  ATen keeps the argmax as int64 flat indices (8 B per OUTPUT element, 411 MB at batch 256) and
+// its backward is one thread per input element walking them (1.55 ms for the 822 MB map, profiles/r05b_steady_state_r50.md).
+// Here the argmax is the window SLOT (0 .. 8, one byte), forward is one pass, backward a gather in ATen's own order (windows by
+// ascending row, then column: the up to four contributions of an input pixel are added in the same order, so dx is bit for bit
+// ATen's) with no atomics.  Algorithmic bytes: forward 4 |x| + 5 |y|, backward 4 |dx| + 5 |dy|.
+// =============================================================================================
+namespace {
+// Plane index from a 2-D grid (y, z): planes may exceed 65 535.  Everything inside a plane is 32-bit arithmetic (a flat 64-bit
+// index costs a 64-bit division per thread: the first version of these kernels ran at ATen's speed because of it).
+__device__ __forceinline__ size_t pool_plane() { return static_cast<size_t>(blockIdx.z) * 65535u + blockIdx.y; }
+
+__device__ __forceinline__ void pool_take(float v, int s, float &best, int &bs) {
+    if (v > best || v != v) {             // ties keep the first maximum in scan order; NaN wins and the LAST NaN is kept
+        best = v;                         // (at::native::max_pool_forward_nchw: `if ((val > maxval) || isnan(val))`)
+        bs = s;
+    }
+}
+
+// V2: one thread per PAIR of outputs (ow = 2 q, 2 q + 1; W a multiple of 4): per input row one aligned float4 (columns
+// 4 q .. 4 q + 3) and one scalar (column 4 q - 1).  Otherwise one thread per output.
+template <bool V2>
+__global__ __launch_bounds__(256) void k_maxpool3x3s2_fwd(const float *__restrict__ x, float *__restrict__ y,
+                                                          unsigned char *__restrict__ slot, size_t planes, int H, int W, int OH, int OW) {
+    const size_t plane = pool_plane();
+    if (plane >= planes) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *xp = x + plane * H * W;
+    if (V2) {
+        const int OW2 = OW / 2;
+        if (i >= OH * OW2) return;
+        const int q = i % OW2, oh = i / OW2;
+        const int h0 = 2 * oh - 1;
+        float b0 = -INFINITY, b1 = -INFINITY;
+        int s0 = (h0 < 0 ? 3 : 0) + (q == 0 ? 1 : 0), s1 = (h0 < 0 ? 3 : 0);      // the windows' first elements inside the map
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int h = h0 + a;
+            if (h < 0 || h >= H) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(xp + h * W + 4 * q);
+            if (q > 0) pool_take(xp[h * W + 4 * q - 1], 3 * a, b0, s0);
+            pool_take(v.x, 3 * a + 1, b0, s0);
+            pool_take(v.y, 3 * a + 2, b0, s0);
+            pool_take(v.y, 3 * a, b1, s1);
+            pool_take(v.z, 3 * a + 1, b1, s1);
+            pool_take(v.w, 3 * a + 2, b1, s1);
+        }
+        const size_t o = (plane * OH + oh) * OW + 2 * q;
+        *reinterpret_cast<float2 *>(y + o) = make_float2(b0, b1);
+        *reinterpret_cast<uchar2 *>(slot + o) = make_uchar2(static_cast<unsigned char>(s0), static_cast<unsigned char>(s1));
+    } else {
+        if (i >= OH * OW) return;
+        const int ow = i % OW, oh = i / OW;
+        const int h0 = 2 * oh - 1, w0 = 2 * ow - 1;
+        float best = -INFINITY;
+        int bs = (h0 < 0 ? 3 : 0) + (w0 < 0 ? 1 : 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int h = h0 + a;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int w = w0 + b;
+                if (w < 0 || w >= W) continue;
+                pool_take(xp[h * W + w], 3 * a + b, best, bs);
+            }
+        }
+        const size_t o = plane * OH * OW + i;
+        y[o] = best;
+        slot[o] = static_cast<unsigned char>(bs);
+    }
+}
+
+// the windows (ph, pw) that contain input pixel (h, w), ph then pw ascending (ATen's order of additions): 2 p - 1 <= h <= 2 p + 1
+__device__ __forceinline__ float pool_gather(const float *__restrict__ dp, const unsigned char *__restrict__ sp, int h, int w,
+                                             int OH, int OW) {
+    const int ph_lo = h / 2, ph_hi = min((h + 1) / 2, OH - 1);
+    const int pw_lo = w / 2, pw_hi = min((w + 1) / 2, OW - 1);
+    float g = 0.f;
+    for (int ph = ph_lo; ph <= ph_hi; ++ph)
+        for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+            const int s = 3 * (h - (2 * ph - 1)) + (w - (2 * pw - 1));
+            if (sp[ph * OW + pw] == s) g += dp[ph * OW + pw];
+        }
+    return g;
+}
+
+// V4: one thread per float4 of dx (W a multiple of 4); otherwise one thread per input element
+template <bool V4>
+__global__ __launch_bounds__(256) void k_maxpool3x3s2_bwd(const float *__restrict__ dy, const unsigned char *__restrict__ slot,
+                                                          float *__restrict__ dx, size_t planes, int H, int W, int OH, int OW) {
+    const size_t plane = pool_plane();
+    if (plane >= planes) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *dp = dy + plane * OH * OW;
+    const unsigned char *sp = slot + plane * OH * OW;
+    if (V4) {
+        const int W4 = W / 4;
+        if (i >= H * W4) return;
+        const int q = i % W4, h = i / W4;
+        // columns 4 q .. 4 q + 3 lie in the windows pw = 2 q, 2 q + 1 (and 2 q + 2 for the last column), row h in ph = h / 2 (and
+        // (h + 1) / 2 for odd h).  Per window row: dy and the slots of the three windows (8 + 4 and 2 + 1 bytes); a selected
+        // add per (pixel, window) in pool_gather's order -- adding +0 where the slot does not match changes no bit.
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = 2 * q;
+        const bool third = c0 + 2 < OW;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ph = h / 2 + r;
+            if (r == 1 && (!(h & 1) || ph >= OH)) break;
+            const int dh = h - 2 * ph + 1;                     // the pixel's row inside window row ph
+            const float2 d01 = *reinterpret_cast<const float2 *>(dp + ph * OW + c0);
+            const uchar2 s01 = *reinterpret_cast<const uchar2 *>(sp + ph * OW + c0);
+            const float d2 = third ? dp[ph * OW + c0 + 2] : 0.f;
+            const int s2 = third ? sp[ph * OW + c0 + 2] : 255;
+            o.x += s01.x == 3 * dh + 1 ? d01.x : 0.f;
+            o.y += s01.x == 3 * dh + 2 ? d01.x : 0.f;
+            o.y += s01.y == 3 * dh ? d01.y : 0.f;
+            o.z += s01.y == 3 * dh + 1 ? d01.y : 0.f;
+            o.w += s01.y == 3 * dh + 2 ? d01.y : 0.f;
+            o.w += s2 == 3 * dh ? d2 : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dx + (plane * H + h) * W + 4 * q) = o;
+    } else {
+        if (i >= H * W) return;
+        dx[plane * H * W + i] = pool_gather(dp, sp, i / W, i % W, OH, OW);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int deepipr_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *slot, size_t planes, int H, int W, void *stream) {
+    if (!x || !y || !slot || planes == 0 || H <= 0 || W <= 0) return fail(DEEPIPR_EINVAL, "maxpool3x3s2_fwd: bad argument");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (static_cast<long long>(H) * W >= (1ll << 30) || planes >= 65535ull * 65535ull) return fail(DEEPIPR_EINVAL, "maxpool3x3s2_fwd: tensor too large");
+    const bool v2 = W % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0 && (reinterpret_cast<uintptr_t>(slot) & 1u) == 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_MAXPOOL, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * H * W + 5.0 * static_cast<double>(planes) * OH * OW;
+    const unsigned py = static_cast<unsigned>(planes < 65535 ? planes : 65535), pz = static_cast<unsigned>((planes + 65534) / 65535);
+    const dim3 grid(static_cast<unsigned>(((v2 ? OH * (OW / 2) : OH * OW) + 255) / 256), py, pz);
+    if (v2) DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_fwd<true>, grid, dim3(256), st, x, y, slot, planes, H, W, OH, OW);
+    else DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_fwd<false>, grid, dim3(256), st, x, y, slot, planes, H, W, OH, OW);
+    return check_launch("maxpool3x3s2_fwd");
+}
+
+int deepipr_maxpool3x3s2_bwd(const float *dy, const unsigned char *slot, float *dx, size_t planes, int H, int W, void *stream) {
+    if (!dy || !dx || !slot || planes == 0 || H <= 0 || W <= 0) return fail(DEEPIPR_EINVAL, "maxpool3x3s2_bwd: bad argument");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (static_cast<long long>(H) * W >= (1ll << 30) || planes >= 65535ull * 65535ull) return fail(DEEPIPR_EINVAL, "maxpool3x3s2_bwd: tensor too large");
+    const bool v4 = W % 4 == 0 && aligned16(dx) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0 && (reinterpret_cast<uintptr_t>(slot) & 1u) == 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_MAXPOOL, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * H * W + 5.0 * static_cast<double>(planes) * OH * OW;
+    const unsigned py = static_cast<unsigned>(planes < 65535 ? planes : 65535), pz = static_cast<unsigned>((planes + 65534) / 65535);
+    const dim3 grid(static_cast<unsigned>(((v4 ? H * (W / 4) : H * W) + 255) / 256), py, pz);
+    if (v4) DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_bwd<true>, grid, dim3(256), st, dy, slot, dx, planes, H, W, OH, OW);
+    else DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_bwd<false>, grid, dim3(256), st, dy, slot, dx, planes, H, W, OH, OW);
+    return check_launch("maxpool3x3s2_bwd");
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// The 1x1 stride-2 projection shortcuts at ImageNet geometry (models/resnet_normal.py:41-42, resnet_passport.py:33-36 with the
+// Bottleneck's channel counts): conv1x1(x, stride 2) = conv1x1(x[:, :, ::2, ::2]) -- a pixel gather in front of a plain
+// stride-1 GEMM, and its backward-data a scatter of the GEMM's result between zeros.  Two streaming kernels instead of the
+// vendor library's NHWC implicit GEMM with three layout transposes and a zero fill per call.  Bytes: 4 (|y| + |touched x|) /
+// 4 (|dx| + |dy|).
+// =============================================================================================
+namespace {
+template <bool V4>
+__global__ __launch_bounds__(256) void k_subsample2(const float *__restrict__ x, float *__restrict__ y, size_t total, int W, int OH, int OW) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;      // V4: one thread per output PAIR
+    if (i >= total) return;
+    if (V4) {
+        const int OW2 = OW / 2;
+        const int q = static_cast<int>(i % OW2);
+        const size_t r = i / OW2;                                               // plane * OH + oh
+        const int oh = static_cast<int>(r % OH);
+        const size_t plane = r / OH;
+        const float4 v = *reinterpret_cast<const float4 *>(x + (plane * 2 * OH + 2 * oh) * W + 4 * q);
+        *reinterpret_cast<float2 *>(y + r * OW + 2 * q) = make_float2(v.x, v.z);
+    } else {
+        const int ow = static_cast<int>(i % OW);
+        const size_t r = i / OW;
+        const int oh = static_cast<int>(r % OH);
+        const size_t plane = r / OH;
+        y[i] = x[(plane * 2 * OH + 2 * oh) * W + 2 * ow];
+    }
+}
+
+template <bool V4>
+__global__ __launch_bounds__(256) void k_upsample2_zero(const float *__restrict__ dy, float *__restrict__ dx, size_t total, int W, int OH, int OW) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;      // V4: one thread per float4 of dx
+    if (i >= total) return;
+    if (V4) {
+        const int W4 = W / 4;
+        const int q = static_cast<int>(i % W4);
+        const size_t r = i / W4;                                                // plane * H + h
+        const int h = static_cast<int>(r % (2 * OH));
+        const size_t plane = r / (2 * OH);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((h & 1) == 0) {
+            const float2 v = *reinterpret_cast<const float2 *>(dy + (plane * OH + (h >> 1)) * OW + 2 * q);
+            o.x = v.x;
+            o.z = v.y;
+        }
+        *reinterpret_cast<float4 *>(dx + r * W + 4 * q) = o;
+    } else {
+        const int w = static_cast<int>(i % W);
+        const size_t r = i / W;
+        const int h = static_cast<int>(r % (2 * OH));
+        const size_t plane = r / (2 * OH);
+        dx[i] = ((h | w) & 1) ? 0.f : dy[(plane * OH + (h >> 1)) * OW + (w >> 1)];
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int deepipr_subsample2(const float *x, float *y, size_t planes, int H, int W, void *stream) {
+    if (!x || !y || planes == 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(DEEPIPR_EINVAL, "subsample2: bad argument (even H, W)");
+    const int OH = H / 2, OW = W / 2;
+    const bool v4 = W % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0;
+    const size_t total = planes * OH * (v4 ? OW / 2 : OW);
+    if ((total + 255) / 256 >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "subsample2: tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_RESAMPLE2, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * OH * (OW + W);
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+    if (v4) DEEPIPR_LAUNCH(prof, k_subsample2<true>, grid, dim3(256), st, x, y, total, W, OH, OW);
+    else DEEPIPR_LAUNCH(prof, k_subsample2<false>, grid, dim3(256), st, x, y, total, W, OH, OW);
+    return check_launch("subsample2");
+}
+
+int deepipr_upsample2_zero(const float *dy, float *dx, size_t planes, int H, int W, void *stream) {
+    if (!dy || !dx || planes == 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(DEEPIPR_EINVAL, "upsample2_zero: bad argument (even H, W)");
+    const int OH = H / 2, OW = W / 2;
+    const bool v4 = W % 4 == 0 && aligned16(dx) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0;
+    const size_t total = planes * H * (v4 ? W / 4 : W);
+    if ((total + 255) / 256 >= (1ull << 31)) return fail(DEEPIPR_EINVAL, "upsample2_zero: tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_RESAMPLE2, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * (static_cast<double>(H) * W + static_cast<double>(OH) * OW);
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+    if (v4) DEEPIPR_LAUNCH(prof, k_upsample2_zero<true>, grid, dim3(256), st, dy, dx, total, W, OH, OW);
+    else DEEPIPR_LAUNCH(prof, k_upsample2_zero<false>, grid, dim3(256), st, dy, dx, total, W, OH, OW);
+    return check_launch("upsample2_zero");
 }
 
 }  // extern "C"

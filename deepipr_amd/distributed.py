@@ -119,10 +119,16 @@ def retire_collectives(seconds=0.0):
     A/B knob); a torch without the call falls back to half a second of pause, as before."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    groups = [pg for pg in list(dist.distributed_c10d._world.pg_map) if _is_rccl(pg)]
+    import time
+    try:                                                        # private c10d state: a torch that moved it gets the pause instead
+        groups = [pg for pg in list(dist.distributed_c10d._world.pg_map) if _is_rccl(pg)]
+    except Exception:
+        if dist.get_backend() == 'nccl':
+            torch.cuda.synchronize()
+            time.sleep(max(seconds, 0.5))
+        return
     if not groups:
         return
-    import time
     torch.cuda.synchronize()
     waited = True
     for pg in groups:
@@ -130,7 +136,10 @@ def retire_collectives(seconds=0.0):
         if wait is None:
             waited = False
         else:
-            wait()
+            try:
+                wait()
+            except Exception:
+                waited = False
     if seconds > 0 or not waited:
         time.sleep(seconds if waited else max(seconds, 0.5))
 

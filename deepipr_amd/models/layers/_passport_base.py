@@ -261,11 +261,9 @@ class PassportLayerBase(nn.Module):
         """The two branches of a dual forward may run this layer in lockstep on halves of one buffer
         (passport_ops.StackShare): both branches take the fused BatchNorm form (learnable scale AND bias on the public one),
         around a plain un-hooked convolution the caller may run once for both."""
-        c = self.conv
         return (self.scale is not None and self.bias is not None and self.fuse_norm and P.bn_is_fusable(self.bn)
                 and x.is_cuda and x.dtype == torch.float32 and self.shareable_conv(x) and self._conv_inside(x)
-                and type(c) is nn.Conv2d and c.kernel_size[0] == c.kernel_size[1] and c.stride[0] == c.stride[1]
-                and isinstance(c.padding, tuple) and c.padding[0] == c.padding[1])
+                and P.conv_plain(self.conv, x))      # conv2d(share=...)'s own test: autocast, process-wide module hooks included
 
     def _layer(self, x, force_passport, ind, residual, conv_out=None, stack=None):
         self.ensure_key(x)

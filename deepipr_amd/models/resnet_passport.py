@@ -18,7 +18,7 @@ from deepipr_amd.models._builders import ind_matters, shared_trunk, trunk_sharin
 from deepipr_amd.models.layers.conv2d import dual_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
-from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, stage_groups, with_wino_weights
+from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, max_pool, stage_groups, with_wino_weights
 
 
 _SHARED_CONV = os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'      # read once, at import (A/B switch)
@@ -171,7 +171,7 @@ class ResNetPassport(nn.Module):
         """-> two handles (out, skip) of the stem's output: it feeds layer1's first conv AND its identity shortcut."""
         from deepipr_amd.models.layers.conv2d import ConvBlock
         if isinstance(self.convbnrelu_1, nn.Sequential):
-            y = self.convbnrelu_1[1](run_layer(self.convbnrelu_1[0], x, force_passport, ind))
+            y = max_pool(self.convbnrelu_1[1], run_layer(self.convbnrelu_1[0], x, force_passport, ind))
             return y, y
         if isinstance(self.convbnrelu_1, ConvBlock):
             return self.convbnrelu_1.forward_fork(x)

@@ -13,9 +13,11 @@ Reference lines each operator stands in for (paths relative to kamwoh/DeepIPR):
 import ctypes
 import functools
 import os
+import threading
 import weakref
 
 import torch
+import torch.utils.weak
 
 from deepipr_amd import _lib
 
@@ -611,6 +613,43 @@ class HipKernels:
                                                    out.numel(), _stream(dev)), 'relu_bwd')
         return dx
 
+    def subsample2(self, x):
+        """x[:, :, ::2, ::2] as a dense tensor (even H, W): the pixel gather in front of a 1x1 stride-2 convolution."""
+        dev = _chk(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_subsample2(_p(x), _p(y), n * c, h, w, _stream(dev)), 'subsample2')
+        return y
+
+    def upsample2_zero(self, dy, x_shape):
+        """The adjoint: dx[:, :, ::2, ::2] = dy, zero elsewhere (every element written)."""
+        dev = _chk(dy)
+        n, c, h, w = x_shape
+        dx = torch.empty(x_shape, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_upsample2_zero(_p(dy), _p(dx), n * c, h, w, _stream(dev)), 'upsample2_zero')
+        return dx
+
+    def maxpool3x3s2_fwd(self, x):
+        """nn.MaxPool2d(3, 2, 1)(x) -> (y, slot): slot = the maximum's window position, one byte per output element."""
+        dev = _chk(x)
+        n, c, h, w = x.shape
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=dev)
+        slot = torch.empty((n, c, oh, ow), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_maxpool3x3s2_fwd(_p(x), _p(y), slot.data_ptr(), n * c, h, w, _stream(dev)), 'maxpool3x3s2_fwd')
+        return y, slot
+
+    def maxpool3x3s2_bwd(self, dy, slot, x_shape):
+        dev = _chk(dy)
+        n, c, h, w = x_shape
+        dx = torch.empty(x_shape, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_maxpool3x3s2_bwd(_p(dy), slot.data_ptr(), _p(dx), n * c, h, w, _stream(dev)), 'maxpool3x3s2_bwd')
+        return dx
+
     def scalar_sums(self, terms, n_a):
         """-> 3 floats {sum of the first n_a single-element tensors, sum of the rest, both}: left-to-right fp32 adds in ONE launch
         (deepipr_scalar_sums) instead of len(terms) one-element aten::add launches."""
@@ -763,30 +802,29 @@ class HipKernels:
         return y
 
     # ---- Winograd images of the weights, once per step (include/deepipr_hip.h: deepipr_conv_wino_transform_multi) ----
-    _wino_images = {}
+    _wino_images = torch.utils.weak.WeakIdKeyDictionary()      # weight tensor OBJECT (by identity) -> [its data address, Uf, Ud]
 
     def wino_image_bytes(self, co, ci):
         return int(_lib.lib().deepipr_conv_wino_image_bytes(co, ci))
 
     def wino_transform(self, weights, backward=True):
         """Writes the Winograd images of `weights` ([Co][Ci][3][3], Co and Ci multiples of 32) in one launch per
-        _lib.WINO_MAX_LAYERS of them -> [(Uf, Ud or None)].  The image buffers are kept per weight address for as long as the
-        weight tensor OBJECT passed here lives (a replayed hipGraph needs them to stay put: pass the parameters themselves, not
-        temporaries) and are valid until the weights change."""
+        _lib.WINO_MAX_LAYERS of them -> [(Uf, Ud or None)].  The image buffers belong to the weight tensor OBJECT passed here
+        (pass the parameters themselves, not temporaries): they stay put while its storage does -- what a replayed hipGraph
+        needs -- are replaced when the object's storage is re-pointed (`p.data = ...`, model.to(), a FlatSGD built after a
+        warm-up forward: ADVICE r05), go when the object goes, and are valid until the weights change."""
         out, todo = [], []
         for w in weights:
             co, ci = w.shape[0], w.shape[1]
             dev = _chk(w)
-            key = (w.data_ptr(), co, ci, dev)
-            buf = self._wino_images.get(key)
+            buf = self._wino_images.get(w)
             nfl = self.wino_image_bytes(co, ci) // 4
-            if buf is None:
-                buf = self._wino_images[key] = [torch.empty(nfl, dtype=torch.float32, device=dev), None]
-                weakref.finalize(w, self._wino_images.pop, key, None)        # the images go when the weight tensor goes
-            if backward and buf[1] is None:
-                buf[1] = torch.empty(nfl, dtype=torch.float32, device=dev)
-            out.append((buf[0], buf[1] if backward else None))
-            todo.append((w, buf[0], buf[1] if backward else None, co, ci, dev))
+            if buf is None or buf[0] != w.data_ptr() or buf[1].numel() != nfl or buf[1].device != w.device:
+                buf = self._wino_images[w] = [w.data_ptr(), torch.empty(nfl, dtype=torch.float32, device=dev), None]
+            if backward and buf[2] is None:
+                buf[2] = torch.empty(nfl, dtype=torch.float32, device=dev)
+            out.append((buf[1], buf[2] if backward else None))
+            todo.append((w, buf[1], buf[2] if backward else None, co, ci, dev))
         for lo in range(0, len(todo), _lib.WINO_MAX_LAYERS):
             chunk = todo[lo:lo + _lib.WINO_MAX_LAYERS]
             arr = (_lib.WinoLayer * len(chunk))()
@@ -973,14 +1011,16 @@ class _SignLoss(torch.autograd.Function):
         return kernels.sign_loss_bwd(dloss.contiguous(), gamma, b, alpha, MARGIN, l2), None, None, None
 
 
-# The data convolution (models/layers/passportconv2d.py:218, conv2d.py:31).  Three kernels of this library stand in for the
-# vendor library where they measured faster on MI355X (tools/conv_bench.py, tools/wgrad_bench.py):
-#   weight gradient     deepipr_conv_wgrad   every 3x3 convolution of stride 1 / 2 it supports
-#   forward             deepipr_conv_fwd     the stride-2 convolutions (3x3 and 1x1): MIOpen wraps its NHWC solvers for
-#   backward-data       deepipr_conv_dgrad   them in layout transposes and zero fills; the stride-1 3x3 stays on MIOpen's
-#                                            Winograd kernels (at par with the direct fp32-MFMA kernel here)
+# The data convolution (models/layers/passportconv2d.py:218, conv2d.py:31).  This library's kernels stand in for the vendor
+# library where they measured faster on MI355X (tools/conv_bench.py, tools/wgrad_bench.py, tools/conv1x1_bench.py):
+#   3x3 stride 1         all three directions on the Winograd kernels (F(2x2, 3x3) forward / backward-data, F(3x3, 2x2) weight
+#                        gradient), CIFAR and ImageNet map widths; the direct implicit GEMMs with DEEPIPR_CONV_ALGO=direct
+#   3x3 / 1x1 stride 2   CIFAR map widths: deepipr_conv_fwd / _dgrad / _wgrad (the vendor library wraps its NHWC solvers for them in
+#                        layout transposes and zero fills)
+#   1x1 (any stride)     forward / backward-data as plain GEMMs over NCHW (_gemm_1x1), weight gradient deepipr_conv_1x1.inc;
+#                        stride 2 at ImageNet widths behind / in front of the pixel gather (deepipr_subsample2 / _upsample2_zero)
 # DEEPIPR_OWN_CONV = auto (default) | all (every shape the kernels support) | 0 (vendor library only);
-# DEEPIPR_OWN_WGRAD=0 switches only the weight gradient off.  All three are bit-reproducible.
+# DEEPIPR_OWN_WGRAD=0 switches only the weight gradient off.  All of them are bit-reproducible.
 OWN_CONV = os.environ.get('DEEPIPR_OWN_CONV', 'auto')
 OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0' and OWN_CONV != '0'
 # the pre-transformed form of the Winograd forward / backward-data kernels (wino_weights): on; and for weights of at most this
@@ -1083,6 +1123,26 @@ def _own_wgrad(x_in, w, stride, pad):
     return bool(kernels.conv_wgrad_workspace(n, ci, w.shape[0], h, wd, w.shape[2], w.shape[3], stride, pad))
 
 
+# A 1x1 pad-0 convolution is a GEMM over NCHW as it stands -- y[n] = W [Co, Ci] @ x[n] [Ci, HW] -- and its backward-data the
+# transposed one.  Forward and backward-data go to the BLAS library as exactly that (a plain library GEMM: no convolution
+# solver to choose -- in immediate mode the vendor convolution library answers some of these with an NHWC implicit GEMM
+# wrapped in layout transposes, profiles/r06b_steady_state_r50.md); the weight gradient is this library's kernel
+# (deepipr_conv_1x1.inc).  Stride 2 (the projection shortcuts at ImageNet map widths, where deepipr_conv_fwd has no
+# instance): the same GEMMs behind / in front of the pixel gather (deepipr_subsample2 / deepipr_upsample2_zero).
+GEMM_1X1 = os.environ.get('DEEPIPR_GEMM_1X1', '1') != '0'
+
+
+def _gemm_1x1(x_shape, w, stride, pad, t):
+    return (GEMM_1X1 and OWN_CONV != '0' and _own_ok(t, w) and w.shape[2] == 1 and pad == 0 and w.shape[1] == x_shape[1]
+            and (stride == 1 or (stride == 2 and x_shape[2] % 2 == 0 and x_shape[3] % 2 == 0)))
+
+
+def _gathered(ctx, x_in):
+    """x_in[:, :, ::2, ::2] of a 1x1 stride-2 convolution: the copy its forward left with the node, or a fresh one."""
+    xs = getattr(ctx, 'gathered', None) if ctx is not None else None
+    return xs if xs is not None else kernels.subsample2(x_in)
+
+
 def _conv_fwd(x_in, w, stride, pad, ctx=None):
     """The data convolution of a node's forward.  ctx: the node -- it keeps the weight's Winograd images of this step
     (_wino_pre; None outside wino_weights()) for its backward-data pass."""
@@ -1091,14 +1151,39 @@ def _conv_fwd(x_in, w, stride, pad, ctx=None):
         ctx.wino_pre = pre
     if _own_fwd(x_in, w, stride, pad):
         return kernels.conv_fwd(x_in, w, stride, pad, pre)
+    if _gemm_1x1(x_in.shape, w, stride, pad, x_in):
+        xs = x_in if stride == 1 else kernels.subsample2(x_in)
+        if ctx is not None and stride == 2:
+            ctx.gathered = xs                          # the weight gradient's operand
+        n, ci, h, wd = xs.shape
+        # bmm with the weight as a stride-0 batch (torch.matmul would fold the batch into the GEMM's rows through a transposed
+        # COPY of the activations: 40 ms per ResNet50 step, profiles/r06c_steady_state_r50_matmul_copy.md)
+        return torch.bmm(w.view(1, w.shape[0], ci).expand(n, -1, -1), xs.view(n, ci, h * wd)).view(n, w.shape[0], h, wd)
     return torch.ops.aten.convolution(x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
 
 
 def _conv_dgrad(dconv, x_in, w, stride, pad, pre=None):
     if _own_dgrad(x_in.shape, w, stride, pad, dconv):
         return kernels.conv_dgrad(dconv, w, x_in.shape, stride, pad, pre)
+    if _gemm_1x1(x_in.shape, w, stride, pad, dconv):
+        n, co, oh, ow = dconv.shape
+        ci = w.shape[1]
+        dxs = torch.bmm(w.view(1, co, ci).transpose(1, 2).expand(n, -1, -1), dconv.reshape(n, co, oh * ow)).view(n, ci, oh, ow)
+        return dxs if stride == 1 else kernels.upsample2_zero(dxs, tuple(x_in.shape))
     return torch.ops.aten.convolution_backward(dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0],
                                                1, [True, False, False])[0]
+
+
+def _wgrad_operand(ctx, x_in, w, stride, pad):
+    """-> (input, stride) deepipr_conv_wgrad takes for this convolution's weight gradient -- the input itself, or the gathered
+    pixels of a 1x1 stride-2 convolution at stride 1 -- or None (the vendor library's weight gradient)."""
+    if _own_wgrad(x_in, w, stride, pad):
+        return x_in, stride
+    if OWN_WGRAD and stride == 2 and _gemm_1x1(x_in.shape, w, stride, pad, x_in):
+        n, ci, h, wd = x_in.shape
+        if kernels.conv_wgrad_workspace(n, ci, w.shape[0], h // 2, wd // 2, 1, 1, 1, 0):
+            return _gathered(ctx, x_in), 1
+    return None
 
 
 def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
@@ -1111,20 +1196,22 @@ def _conv_bwd_acc(ctx, dconv, x_in, w, stride, pad, dg, db, m, defer=None):
     need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     if not (need_dx or need_dw):                      # frozen first layer: nothing flows further
         return None, None, False
-    if need_dw and _own_wgrad(x_in, w, stride, pad):
+    opnd = _wgrad_operand(ctx, x_in, w, stride, pad) if need_dw else None
+    if opnd is not None:
         dconv = dconv.contiguous()
+        xw, sw = opnd
         if w.shape[1] % 32 == 0:                       # (every instance but the 3-channel stem's adds the rank-2 term in its reduction)
-            dw = kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad, dg, db, m)
+            dw = kernels.conv_wgrad(xw, dconv, w.shape, sw, pad, dg, db, m)
         else:                                          # the 3-channel stem instance has no fused rank-2 term: the separate accumulate pass
-            dw = kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(x_in, dconv, w.shape, stride, pad))
+            dw = kernels.gamma_beta_bwd_acc(dg, db, m, kernels.conv_wgrad(xw, dconv, w.shape, sw, pad))
         dx = _conv_dgrad(dconv, x_in, w, stride, pad, getattr(ctx, 'wino_pre', None)) if need_dx else None
         return dx, dw, False
-    own_dx = need_dx and _own_dgrad(x_in.shape, w, stride, pad, dconv)
+    own_dx = need_dx and (_own_dgrad(x_in.shape, w, stride, pad, dconv) or _gemm_1x1(x_in.shape, w, stride, pad, dconv))
     dx, dw, _ = torch.ops.aten.convolution_backward(
         dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
         [need_dx and not own_dx, need_dw, False])
     if own_dx:
-        dx = kernels.conv_dgrad(dconv.contiguous(), w, x_in.shape, stride, pad, getattr(ctx, 'wino_pre', None))
+        dx = _conv_dgrad(dconv.contiguous(), x_in, w, stride, pad, getattr(ctx, 'wino_pre', None))
     if need_dw:
         dw = dw.contiguous()
         if defer is not None:
@@ -1246,15 +1333,17 @@ class _Conv2dOwn(torch.autograd.Function):
         r2 = ctx.share.rank2 if ctx.share is not None else None     # the passport branch's rank-2 term rides in the wgrad
         if ctx.share is not None:
             ctx.share.rank2 = None
-        if need_dw and _own_wgrad(x, w, stride, pad):
+        opnd = _wgrad_operand(ctx, x, w, stride, pad) if need_dw else None
+        if opnd is not None:
+            xw, sw = opnd
             if r2 is not None and w.shape[1] % 32 == 0:
-                dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad, *r2)
+                dw = kernels.conv_wgrad(xw, dy, w.shape, sw, pad, *r2)
                 r2 = None
             else:
-                dw = kernels.conv_wgrad(x, dy, w.shape, stride, pad)
+                dw = kernels.conv_wgrad(xw, dy, w.shape, sw, pad)
             need_dw = False
-        if need_dx and _own_dgrad(x.shape, w, stride, pad, dy):
-            dx = kernels.conv_dgrad(dy, w, x.shape, stride, pad, getattr(ctx, 'wino_pre', None))
+        if need_dx and (_own_dgrad(x.shape, w, stride, pad, dy) or _gemm_1x1(x.shape, w, stride, pad, dy)):
+            dx = _conv_dgrad(dy, x, w, stride, pad, getattr(ctx, 'wino_pre', None))
             need_dx = False
         if need_dx or need_dw:
             vdx, vdw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [1, 1], False,
@@ -1271,23 +1360,33 @@ _GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS = _nnmod._global_forward_hooks, _nnmod.
 _GLOBAL_BWD_HOOKS, _GLOBAL_BWD_PRE_HOOKS = _nnmod._global_backward_hooks, _nnmod._global_backward_pre_hooks
 
 
-def conv2d(conv, x, share=None):
-    """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked for which this library has a kernel in at least one
-    direction goes through _Conv2dOwn; anything else is the module call.  share: a StackShare whose private-branch node
-    leaves its dgamma / dbeta for this convolution's weight gradient (the caller has checked that the conv is a plain,
-    un-hooked one: PassportLayerBase.shareable_conv) -- always through _Conv2dOwn then."""
-    if (OWN_CONV != '0' and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+def conv_plain(conv, x):
+    """THE eligibility test of the own-kernel route, in one place: conv(x) may bypass Module.__call__ -- a plain
+    bias-free square nn.Conv2d on the GPU that nobody hooked (module hooks, the process-wide module hooks that
+    Module.__call__ also runs -- FlopCounterMode, register_module_forward_hook --, a wrapped forward) outside autocast.
+    conv2d() routes by it, and PassportLayerBase.stackable() asks it before a dual forward commits to lockstep branches
+    (conv2d(share=...) has no module-call fallback)."""
+    return (OWN_CONV != '0' and x.is_cuda and conv.bias is None and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
             and conv.padding_mode == 'zeros' and conv.stride[0] == conv.stride[1]
             and isinstance(conv.padding, tuple) and conv.padding[0] == conv.padding[1]
             and conv.kernel_size[0] == conv.kernel_size[1]
             and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or conv._backward_pre_hooks)
             and not (_GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS or _GLOBAL_BWD_HOOKS or _GLOBAL_BWD_PRE_HOOKS)   # Module.__call__ runs them
             and not torch.is_autocast_enabled()
-            and type(conv) is torch.nn.Conv2d and 'forward' not in conv.__dict__):     # nor wrapped its forward
+            and type(conv) is torch.nn.Conv2d and 'forward' not in conv.__dict__)      # nor wrapped its forward
+
+
+def conv2d(conv, x, share=None):
+    """conv(x) for an nn.Conv2d.  A plain convolution nobody hooked (conv_plain) for which this library has a kernel in at
+    least one direction goes through _Conv2dOwn; anything else is the module call.  share: a StackShare whose private-branch
+    node leaves its dgamma / dbeta for this convolution's weight gradient (the caller has asked conv_plain:
+    PassportLayerBase.stackable) -- always through _Conv2dOwn then."""
+    if conv_plain(conv, x):
         st, pd, w = conv.stride[0], conv.padding[0], conv.weight
         if share is not None:
             return _Conv2dOwn.apply(x, w, st, pd, share)
         if ((torch.is_grad_enabled() and w.requires_grad and _own_wgrad(x, w, st, pd)) or _own_fwd(x, w, st, pd)
+                or _gemm_1x1(x.shape, w, st, pd, x)
                 or (torch.is_grad_enabled() and x.requires_grad and _own_dgrad(x.shape, w, st, pd, x))):
             return _Conv2dOwn.apply(x, w, st, pd)
     if share is not None:
@@ -1569,15 +1668,18 @@ def passport_bn_layer(x, weight, skey, key, b, m, bn, alpha, relu, stride, pad, 
     return ((y, y2) if residual is not None else y), gamma, beta, loss, acc, bits
 
 
-_WINO_CONVS = weakref.WeakKeyDictionary()      # model -> its 3x3 stride-1 convolutions that have a Winograd image
-_WINO_TABLE = None        # {weight address: (weight shape, Uf, Ud)} while a net's forward pass is under wino_weights()
+_WINO_CONVS = weakref.WeakKeyDictionary()      # model -> (module count, its 3x3 stride-1 convolutions that have a Winograd image)
+# {weight address: (weight shape, Uf, Ud)} while a net's forward pass is under wino_weights() -- per THREAD (threaded
+# forwards of replicas, nn.DataParallel style, must not see each other's tables)
+_WINO_TLS = threading.local()
 
 
 def _wino_pre(w):
     """(Uf, Ud) of this weight for the current forward pass, or None."""
-    if _WINO_TABLE is None:
+    table = getattr(_WINO_TLS, 'table', None)
+    if table is None:
         return None
-    hit = _WINO_TABLE.get(w.data_ptr())
+    hit = table.get(w.data_ptr())
     return hit[1:] if hit is not None and hit[0] == tuple(w.shape) else None
 
 
@@ -1592,21 +1694,25 @@ class wino_weights:
 
     def __init__(self, model, x):
         self.model = model
-        self.on = bool(x.is_cuda) and WINO_PRE and x.shape[0] >= WINO_PRE_MIN_BATCH and kernels.conv_algo_is_winograd()
+        self.on = (torch.is_tensor(x) and bool(x.is_cuda) and WINO_PRE and x.shape[0] >= WINO_PRE_MIN_BATCH
+                   and kernels.conv_algo_is_winograd())
 
     def _convs(self):
-        convs = _WINO_CONVS.get(self.model)
-        if convs is None:
-            convs = _WINO_CONVS[self.model] = [
-                m for m in self.model.modules()
+        # the list is kept per model and rebuilt when the model's module set changed (model surgery after a first forward:
+        # a replaced convolution must get its image, a removed one must not be transformed every step)
+        mods = list(self.model.modules())
+        key = (len(mods), sum(id(m) for m in mods))
+        hit = _WINO_CONVS.get(self.model)
+        if hit is None or hit[0] != key:
+            hit = _WINO_CONVS[self.model] = (key, [
+                m for m in mods
                 if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
                 and m.groups == 1 and m.dilation == (1, 1) and m.bias is None and m.padding_mode == 'zeros'
-                and m.in_channels % 32 == 0 and m.out_channels % 32 == 0]
-        return convs
+                and m.in_channels % 32 == 0 and m.out_channels % 32 == 0])
+        return hit[1]
 
     def __enter__(self):
-        global _WINO_TABLE
-        self.before = _WINO_TABLE
+        self.before = getattr(_WINO_TLS, 'table', None)
         if not self.on or self.before is not None:          # (a nested forward keeps the outer table)
             return self
         ws = [m.weight for m in self._convs() if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
@@ -1615,21 +1721,21 @@ class wino_weights:
             backward = torch.is_grad_enabled()           # (the backward-data images only when a backward pass can follow)
             with torch.no_grad():
                 imgs = kernels.wino_transform(ws, backward=backward)
-            _WINO_TABLE = {w.data_ptr(): (tuple(w.shape),) + pair for w, pair in zip(ws, imgs)}
+            _WINO_TLS.table = {w.data_ptr(): (tuple(w.shape),) + pair for w, pair in zip(ws, imgs)}
         return self
 
     def __exit__(self, *exc):
-        global _WINO_TABLE
-        _WINO_TABLE = self.before
+        _WINO_TLS.table = self.before
         return False
 
 
 def with_wino_weights(forward):
-    """Decorator for a net's forward(self, x, ...) / forward_dual: the whole pass under wino_weights(self, x)."""
+    """Decorator for a net's forward(self, x, ...) / forward_dual: the whole pass under wino_weights(self, x); x may be
+    passed by keyword."""
     @functools.wraps(forward)
-    def wrapped(self, x, *args, **kwargs):
-        with wino_weights(self, x):
-            return forward(self, x, *args, **kwargs)
+    def wrapped(self, *args, **kwargs):
+        with wino_weights(self, args[0] if args else kwargs.get('x')):
+            return forward(self, *args, **kwargs)
     return wrapped
 
 
@@ -1854,6 +1960,39 @@ def gn_affine_relu(x, gamma, beta, norm, relu=True):
     """Fused W-less branch: GroupNorm / InstanceNorm2d + per-channel gamma/beta (None = 1 / 0) + ReLU."""
     cfg = (0.0, bool(relu), 1, 0, norm_groups(norm), norm.eps, False)
     return _PassportGNLayer.apply(x, None, None, None, gamma, beta, None, None, cfg)[0]
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) of the ImageNet stem (models/resnet_passport.py:94-98): one pass forward, a one-byte argmax, a
+    gather backward in ATen's order (bit-identical to F.max_pool2d both ways)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y, slot = kernels.maxpool3x3s2_fwd(x)
+        ctx.save_for_backward(slot)
+        ctx.x_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        slot, = ctx.saved_tensors
+        return kernels.maxpool3x3s2_bwd(dy.contiguous(), slot, ctx.x_shape)
+
+
+def max_pool(pool, x):
+    """pool(x) for an nn.MaxPool2d: this library's kernel for the stem's 3x3 / 2 / pad 1 pool of a float32 CUDA map nobody
+    hooked, the module call otherwise."""
+    def two(v):
+        return (v, v) if isinstance(v, int) else tuple(v)
+    if (type(pool) is torch.nn.MaxPool2d and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and two(pool.kernel_size) == (3, 3) and two(pool.stride) == (2, 2) and two(pool.padding) == (1, 1)
+            and two(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices
+            and not (pool._forward_hooks or pool._forward_pre_hooks or pool._backward_hooks or pool._backward_pre_hooks)
+            and not (_GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS or _GLOBAL_BWD_HOOKS or _GLOBAL_BWD_PRE_HOOKS)
+            and not torch.is_autocast_enabled() and 'forward' not in pool.__dict__):
+        return _MaxPool3x3s2.apply(x)
+    return pool(x)
 
 
 class _CrossEntropyTop1(torch.autograd.Function):

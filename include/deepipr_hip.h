@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 10
+#define DEEPIPR_ABI_VERSION 11
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -90,7 +90,9 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV_WINO_WGRAD 29     /* Winograd F(3x3, 2x2) weight gradient: EXECUTED FLOPs */
 #define DEEPIPR_K_CONV_WINO_WEIGHTS 30   /* the Winograd weight transform of the pre-transformed form (bytes: 36 in + 66 out per filter and direction) */
 #define DEEPIPR_K_CONV1X1_WGRAD 31       /* 1x1 stride-1 weight gradient (deepipr_conv_1x1.inc): FLOPs */
-#define DEEPIPR_PROFILE_KERNELS 32
+#define DEEPIPR_K_MAXPOOL 32              /* 3x3 stride-2 max-pool forward / backward (bytes) */
+#define DEEPIPR_K_RESAMPLE2 33            /* the stride-2 pixel gather / zero-interleaving scatter around a 1x1 stride-2 convolution (bytes) */
+#define DEEPIPR_PROFILE_KERNELS 34
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -265,8 +267,8 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * kernel (16 B/element) instead of by a separate add pass.  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
  * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
  * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
-#define DEEPIPR_SYNC_WORDS (2 * (256 * 30 * 4 + 2048) + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, 2 x 1024 for 32 / 64 slices, + flags */
-#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * (256 * 30 * 4 + 2048))
+#define DEEPIPR_SYNC_WORDS (2 * (256 * 30 * 4 + 4096) + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, 2 x 2048 for 32 / 64 slices (two slot sets: ABI v11), + flags */
+#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * (256 * 30 * 4 + 4096))
 int deepipr_set_resident(int mode);
 #ifdef DEEPIPR_TEST_HOOKS
 /* MEASUREMENT / TEST BUILD ONLY (libdeepipr_hip_trace.so, `make -C deepipr_amd/csrc trace`): the production library
@@ -429,6 +431,25 @@ int deepipr_relu_bwd(const float *dy, const float *out, float *dx, size_t n, voi
  * separate kernel (12 B/element more).  dy2 == NULL is deepipr_relu_bwd. */
 int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float *dx, size_t n, void *stream);
 
+/* ------------------------------------------------------------------ 3x3 stride-2 pad-1 max-pool (the ImageNet stem)
+ * y[plane][oh][ow] = max over x[plane][2 oh - 1 .. 2 oh + 1][2 ow - 1 .. 2 ow + 1] inside the map, OH = (H - 1) / 2 + 1 (OW alike);
+ * slot[plane][oh][ow] = 3 a + b of the maximum's window position (first maximum in scan order, NaN wins -- ATen's rule); the
+ * backward adds dy into dx at the recorded positions, windows in ATen's order (bit-identical dx), no atomics.  planes = N * C;
+ * y / dy: planes * OH * OW floats; slot: as many BYTES (the caller's buffer; ATen keeps int64 indices).
+ * replaces: nn.MaxPool2d(3, 2, 1) and its backward, models/resnet_passport.py:94-98 (the 224 x 224 stem). */
+int deepipr_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *slot, size_t planes, int H, int W, void *stream);
+int deepipr_maxpool3x3s2_bwd(const float *dy, const unsigned char *slot, float *dx, size_t planes, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------ 1x1 stride-2 convolution = pixel gather + stride-1 GEMM
+ * deepipr_subsample2: y[plane][oh][ow] = x[plane][2 oh][2 ow] (H, W even; planes = N * C).  deepipr_upsample2_zero: its adjoint,
+ * dx[plane][2 oh][2 ow] = dy[plane][oh][ow], zero elsewhere (every element of dx is written: no separate fill).  With them a
+ * 1x1 stride-2 pad-0 convolution is conv1x1(subsample2(x)) in all three directions -- forward a plain GEMM, weight gradient
+ * deepipr_conv_wgrad(.., k = 1, stride 1) on the gathered input, backward-data the transposed GEMM followed by the scatter.
+ * replaces: the NHWC implicit-GEMM solvers + layout transposes + zero fill the vendor library runs for the projection shortcuts,
+ *           models/resnet_normal.py:41-42 / models/resnet_passport.py:33-36 at ImageNet map widths. */
+int deepipr_subsample2(const float *x, float *y, size_t planes, int H, int W, void *stream);
+int deepipr_upsample2_zero(const float *dy, float *dx, size_t planes, int H, int W, void *stream);
+
 /* ------------------------------------------------------------------ data convolution: weight gradient
  * dW[co][ci][r][s] = sum_{n,oh,ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + r - pad][ow*stride + s - pad]
  * on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation in a fixed order --
@@ -438,8 +459,15 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
  * dW[co][k] += dgamma[co] * m[0][k] + dbeta[co] * m[1][k]  (deepipr_gamma_beta_bwd_acc's arithmetic), so the shared
  * weight's three-way gradient is complete when it is first written.
  * Supported (H, W: the INPUT map; dy is [N][Co][H / stride][W / stride]; Ci, Co multiples of 64 unless said otherwise):
- *   3x3 pad 1 stride 1   output maps 4 / 8 / 16 / 32 wide, H a multiple of the row band 4 / 8 / 4 / 2, N even on 4-wide maps;
+ *   3x3 pad 1 stride 1   with the default algorithm (deepipr_conv_set_algo(1): Winograd F(3x3, 2x2), fp32 arithmetic) maps 4 / 8 /
+ *                        16 / 32 and 14 / 28 / 56 wide of any even height (whole tile-row bands: H / 2 a multiple of 2 / 4 / 2 / 1
+ *                        on the first four) and 7 x 7 maps, Ci a multiple of 32, any N (ragged image groups are masked), the
+ *                        rank-2 term included (deepipr_conv_wgrad_workspace_bytes is the authority);
+ *                        with the direct algorithm (deepipr_conv_set_algo(0)) or bf16x3 arithmetic: output maps 4 / 8 / 16 / 32
+ *                        wide, H a multiple of the row band 4 / 8 / 4 / 2, N even on 4-wide maps;
  *   3x3 pad 1 stride 2   output maps 4 / 8 / 16 wide, output height a multiple of 4 / 4 / 2;
+ *   1x1 pad 0 stride 1   planes of H * W = a multiple of 64, of 56, of 28, or exactly 49 positions (the Bottleneck's
+ *                        convolutions at 56 / 28 / 14 / 7-wide maps, models/resnet_normal.py:30-49; any N; ABI v11);
  *   1x1 pad 0 stride 2   output maps 4 / 8 / 16 wide, output height a multiple of 4 / 8 / 4, N even on 4-wide maps
  *                        (the projection shortcuts; models/resnet_passport.py:33-36);
  *   3x3 pad 1 stride 1 with Ci = 3 on 32-wide maps, H a multiple of 4 (the CIFAR stem): NO fused rank-2 term -- with dgamma /

@@ -124,6 +124,8 @@ def test_resnet50_bottleneck_passport_on_imagenet_shapes():
     assert float((o_p.double() - o_r).abs().max()) <= 1e-4 * s32, (float((o_p.double() - o_r).abs().max()), s32)
     out_p, out_r = prod(x.to(DEV)), ref(x)
     scale = float(out_r.abs().max())
+    # the fp32 CPU oracle on a batch of 8 (40 norm layers over 8 images: its own rounding is at the 1e-4 level here -- the tight
+    # bars are the float64 comparison above and test_whole_net_backward_within_1e4_with_relu_kinks_gated[resnet50_imagenet])
     assert float((out_p.cpu() - out_r).abs().max()) <= 1e-3 * scale, (float((out_p.cpu() - out_r).abs().max()), scale)
     passports = {nm: m for nm, m in prod.named_modules() if getattr(m, 'sign_loss', None) is not None
                  and hasattr(m, 'conv')}
@@ -160,6 +162,64 @@ def test_resnet50_bottleneck_passport_on_imagenet_shapes():
             assert torch.allclose(bp[name].cpu(), bb, rtol=1e-3, atol=1e-5), name
 
 
+def test_resnet50_config5_full_batch_train_step_properties():
+    """BASELINE config 5 AT ITS SIZE: ResNet50 passport variant, 3x224x224, 1000 classes, 256 images -- one train step through
+    the product's own step (train_step_v1: forward, CE + sign loss, backward, SGD).  The float64 oracle cannot hold a whole net at
+    this batch in test time, so the step is held to size-independent properties: everything finite; gamma of every passport
+    layer (a function of weights and keys only) equal to a float64 evaluation of the reference's get_scale
+    (models/layers/passportconv2d.py:142-158) -- sign bits exact wherever |gamma| > 1e-6, values within 1e-4; the sign loss equal to
+    its float64 formula; no exchange wait expired; the post-step weights moved, finite, and by no more than lr * (|grad| bound)."""
+    from deepipr_amd.experiments.trainer import train_step_v1
+    from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
+    from deepipr_amd.models.resnet_passport import ResNet50Passport
+    from deepipr_amd.passport_ops import kernels as K
+    cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet50_passport.json')))
+    kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': 'bn', 'key_type': 'random',
+                                              'sl_ratio': ALPHA})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prod = ResNet50Passport(num_classes=1000, passport_kwargs=kw).to(DEV)
+    n = 256
+    x, y = patterns.batch(n, 3, 224, 224, 1000)
+    prod.train()
+    with torch.no_grad():
+        prod(x[:2].to(DEV))                                   # draws the random keys
+    patterns.fill_state(prod)
+    for m in prod.modules():
+        if hasattr(m, 'invalidate_key_cache'):
+            m.invalidate_key_cache()
+    before = {k: v.detach().clone() for k, v in prod.named_parameters()}
+    name_of = {id(v): k for k, v in prod.named_parameters()}      # (a passport layer's weight is registered twice: .weight / .conv.weight)
+    opt = torch.optim.SGD(prod.parameters(), **SGD)
+    loss, sign_loss, _ = train_step_v1(prod, opt, x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and np.isfinite(float(sign_loss)) and float(loss) > 0
+    assert K.sync_timeouts() == 0
+    layers = {nm: m for nm, m in prod.named_modules() if getattr(m, 'sign_loss', None) is not None and hasattr(m, 'conv')}
+    assert len(layers) == 10
+    total = 0.0
+    for name, m in layers.items():
+        w64 = before[name_of[id(m.conv.weight)]].double()
+        st, pd = m.conv.stride, m.conv.padding
+        g64 = torch.nn.functional.conv2d(m.skey.double(), w64, None, st, pd).mean(dim=(0, 2, 3))
+        g = m.sign_loss.scale_cache.detach().view(-1).double()
+        assert float((g - g64).abs().max()) <= 1e-4 * max(1.0, float(g64.abs().max())), name
+        sure = g64.abs() > 1e-6
+        assert torch.equal(g.sign()[sure], g64.sign()[sure]), name                           # signature bits
+        b = m.b.double()
+        total += float((ALPHA * torch.relu(-b * g64 + 0.1)).sum() + 1e-5 * (g64 ** 2).sum())  # models/losses/sign_loss.py:27,53
+    assert abs(float(sign_loss) - total) <= 1e-4 * max(1.0, abs(total))
+    moved = 0
+    for name, p in prod.named_parameters():
+        assert torch.isfinite(p).all(), name
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        step = (p.detach() - before[name]).abs().max()
+        bound = SGD['lr'] * (p.grad.abs().max() + SGD.get('weight_decay', 0.0) * before[name].abs().max())
+        assert float(step) <= 1.0001 * float(bound) + 1e-12, name
+        moved += int(float(step) > 0)
+    assert moved >= 0.95 * len(before)
+
+
 # ----------------------------------------------------------------------------- whole net, tight
 class _RecordingF:
     """torch.nn.functional for oracle/torch_ref.py with relu() recording, per layer, which pre-activations sit within
@@ -193,6 +253,11 @@ WHOLE_NET_CASES = {
     # ImageNet geometry (models/resnet_passport.py:94-98: 7x7 / 2 stem + max-pool, 1000 classes; 56 / 28 / 14 / 7-wide maps:
     # the Winograd kernels' 28-of-32-lane instances, the vendor library for the stem, the stride-2 and the weight gradients)
     'resnet18_v1_imagenet': ('resnet18', False, 32, 1000, 'bn', 224),
+    # BASELINE config 5 (round 6): ResNet50 passport variant at ImageNet geometry, batch 32 -- every convolution kind of the
+    # Bottleneck net (3x3 stride-1 Winograd in all three directions at 56 / 28 / 14 / 7-wide maps, the 1x1 GEMM route + the own 1x1
+    # weight gradient, the 1x1 stride-2 gather / scatter, the own max-pool, ten passport layers on 7x7 maps) under the same
+    # 1e-4 bar as the other configurations
+    'resnet50_imagenet': ('resnet50', False, 32, 1000, 'bn', 224),
 }
 
 
@@ -200,13 +265,20 @@ def _whole_net_pair(arch, private, n, ncls, norm, hw=32):
     """Product net on the GPU and the oracle's net with the same pattern-filled weights, keys and batch."""
     from deepipr_amd.experiments.utils import construct_passport_kwargs_from_dict
     from oracle.cases import resnet18_config
-    cfg = resnet18_config() if arch == 'resnet18' else alexnet_config()
+    if arch == 'resnet50':
+        cfg = json.load(open(os.path.join(ROOT, 'passport_configs', 'resnet50_passport.json')))
+    else:
+        cfg = resnet18_config() if arch == 'resnet18' else alexnet_config()
     kw = construct_passport_kwargs_from_dict({'passport_config': cfg, 'norm_type': norm, 'key_type': 'random',
                                               'sl_ratio': ALPHA})
     kw_ref = torch_ref.passport_kwargs_from_config(cfg, norm, 'random', ALPHA)
     torch.manual_seed(0)
     np.random.seed(0)
-    if arch == 'resnet18':
+    if arch == 'resnet50':
+        from deepipr_amd.models.resnet_passport import ResNet50Passport
+        prod = ResNet50Passport(num_classes=ncls, passport_kwargs=kw).to(DEV)
+        ref = torch_ref.resnet50_ref(num_classes=ncls, passport_kwargs=kw_ref)
+    elif arch == 'resnet18':
         from deepipr_amd.models.resnet_passport import ResNet18Passport
         from deepipr_amd.models.resnet_passport_private import ResNet18Private
         prod = (ResNet18Private if private else ResNet18Passport)(num_classes=ncls, passport_kwargs=kw).to(DEV)
@@ -335,9 +407,22 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
         m.register_forward_hook(gate(near[name], torch.float64))
     prod_pools = dict((k, m) for k, m in prod.named_modules() if isinstance(m, torch.nn.MaxPool2d))
     assert set(prod_pools) == set(ties)
+    from deepipr_amd.models import resnet_passport as _rp
+    own_pool, pool_gates = _rp.max_pool, {}
     for name, m in pools:                                      # near-tie pooling windows: gated out of both nets
         m.register_forward_hook(gate(ties[name], torch.float64))
-        prod_pools[name].register_forward_hook(gate(ties[name], torch.float32))
+        if arch.startswith('resnet'):
+            # the ResNet stem's pool runs through passport_ops.max_pool -- this library's kernel (a module hook would send it
+            # back to the module call): gate the result of THAT call instead, so the test exercises deepipr_maxpool3x3s2_*
+            pool_gates[id(prod_pools[name])] = gate(ties[name], torch.float32)
+        else:
+            prod_pools[name].register_forward_hook(gate(ties[name], torch.float32))
+
+    def gated_pool(pool, t):
+        out = own_pool(pool, t)
+        g = pool_gates.get(id(pool))
+        return out if g is None else g(pool, None, out)
+    monkeypatch.setattr(_rp, 'max_pool', gated_pool)
     prod_layers = dict(_layer_modules(prod, PASSPORT_TYPES + (ConvBlock,)))
     assert set(prod_layers) == set(near)
     # ConvBlocks: a module hook sees the layer's own output (the tail add happens outside the module call).  Passport

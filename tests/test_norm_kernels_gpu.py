@@ -124,6 +124,33 @@ def test_single_pass_backward_sums_two_incoming_gradients(K, shape):
     assert K.sync_timeouts() == 0
 
 
+@pytest.mark.parametrize('shape', [(64, 64, 56, 56), (96, 64, 56, 56), (32, 24, 112, 112), (48, 256, 56, 56), (256, 128, 28, 28),
+                                   (128, 8, 112, 112), (128, 20, 112, 112), (256, 64, 112, 112)],      # 64 / 32 slices per channel: the two-set regions
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_ranges_in_one_launch_equal_one_launch_per_range(shape, tmp_path):
+    """Round 6: the channel ranges of a map beyond the register file run inside ONE launch (k_bn_res_fwd_ranges /
+    k_bn_res_bwd_ranges: a workgroup walks its ranges itself, the exchange alternating between two slot sets) instead of one
+    launch per range.  Same plan, same unit -> thread mapping, same reduction order: every output is bit for bit the per-range
+    form's (DEEPIPR_BN_RANGES=0), ragged last ranges included, and no exchange wait expires."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for mode in ('1', '0'):
+        out = str(tmp_path / ('ranges%s.npz' % mode))
+        env = dict(os.environ, DEEPIPR_BN_RANGES=mode)
+        subprocess.run([sys.executable, os.path.join(here, 'norm_ranges_case.py')] + [str(v) for v in shape] + [out],
+                       check=True, env=env, timeout=600)
+        got[mode] = np.load(out)
+    a, b = got['1'], got['0']
+    assert int(a['timeouts']) == 0 and int(b['timeouts']) == 0
+    assert a['passes'][1] >= 2 and np.array_equal(a['passes'], b['passes'])
+    for k in ('y', 'table', 'rm', 'rv', 'nbt', 'dx', 'dgamma', 'dbeta'):
+        assert np.array_equal(a[k], b[k]), k
+    assert int(a['nbt'].reshape(-1)[0]) == 4                   # counted once per call, not once per range
+
+
 # ----------------------------------------------------------------------------- maps too large for one pass
 LARGE_MAPS = [
     # (N, C, H, W)            forward            backward
