@@ -392,6 +392,9 @@ def main():
     ap.add_argument('--unstaged', action='store_true', help='N > 1: forward + backward as ONE graph, the whole exchange '
                     'after it (round-2 form) instead of the staged, overlapped exchange')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    ap.add_argument('--stage-host-wait-histogram', action='store_true',
+                    help='N > 1 (or DEEPIPR_FORCE_DDP=1): 200 extra steps; p50 / p99 / max of the host waits on each backward '
+                         "stage's event (the host sits in the staged step's loop three times per step)")
     ap.add_argument('--dry-run', action='store_true', help='launch plumbing only: no workload (CPU-testable)')
     args = ap.parse_args()
     t_start = time.perf_counter()
@@ -677,11 +680,19 @@ def main():
         stage_plan = graphed.describe()
         opt.exposed_events = []
         graphed.host_times = {}
-        for i in range(20):
+        extra = 200 if args.stage_host_wait_histogram else 20
+        for i in range(extra):
             step(i)
         torch.cuda.synchronize()
         ht, graphed.host_times = graphed.host_times, None
-        stage_plan['host_us_per_step'] = {k: round(1e6 * v / 20, 1) for k, v in ht.items() if not k.startswith('calls_')}
+        waits = ht.pop('waits', {})
+        stage_plan['host_us_per_step'] = {k: round(1e6 * v / extra, 1) for k, v in ht.items() if not k.startswith('calls_')}
+        if waits:
+            # how long the host sat in Event.synchronize() behind each backward stage before it could enqueue that stage's bucket
+            stage_plan['host_wait_us'] = {
+                'stage_%d' % k: {'n': len(v), 'p50': round(1e6 * float(np.percentile(v, 50)), 1),
+                                 'p99': round(1e6 * float(np.percentile(v, 99)), 1), 'max': round(1e6 * max(v), 1)}
+                for k, v in sorted(waits.items())}
         if opt.exposed_events:
             exposed_us = 1000.0 * sum(a.elapsed_time(b) for a, b in opt.exposed_events) / len(opt.exposed_events)
             exposed_us = D.max_over_ranks(exposed_us, device)
@@ -753,6 +764,8 @@ def main():
                  'bn_bwd_reduce': 'backward channel sums (8 B/elt)', 'bn_stats': 'batch statistics (4 B/elt)',
                  'affine_bwd': 'affine backward: read dy + xhat, write dxhat (12 B/elt)',
                  'affine_fwd': 'affine forward (8 B/elt)', 'sgd': 'fused SGD over the flat buffers (20 B/param)',
+                 'maxpool': '3x3 stride-2 max-pool of the ImageNet stem, forward / backward with a one-byte argmax (4 B per input + 5 B per output element)',
+                 'resample2': 'stride-2 pixel gather / zero-interleaving scatter around the 1x1 stride-2 convolutions',
                  # the kernel pair the north star names: gamma / beta of ALL passport layers in one launch (W read once,
                  # 4 B/weight) and the rank-2 update accumulated into each layer's wgrad (8 B/weight, one launch per layer)
                  'gamma_beta_fwd': 'passport GEMV, all passport layers in one launch: gamma, beta = W . pooled keys (4 B/weight)',
@@ -760,7 +773,7 @@ def main():
                  # pre-transformed form of the Winograd forward / backward-data kernels: ONE launch per step writes the images
                  # G g G^T of every 3x3 stride-1 weight (36 B in, 66 B out per filter and direction)
                  'conv_wino_weights': 'Winograd weight transform, all 3x3 stride-1 layers in one launch (36 B in + 2 x 66 B out per filter)'}
-    NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd', 'conv_wino_weights')
+    NOT_DOMINANT = ('sgd', 'gamma_beta_fwd', 'gamma_beta_bwd', 'conv_wino_weights', 'maxpool', 'resample2')
     hbm = None
     if out['exchange_timeouts']:
         out['roofline_refused'] = ('an in-launch exchange of the single-pass kernels timed out (%d buffer(s)): their '
@@ -812,6 +825,11 @@ def main():
                               'products, fp32 accumulation; split-K partial tiles summed by k_conv_wgrad_reduce, timed apart)', 6.0),
             'conv_wgrad': ('k_conv3x3_wgrad / k_conv1x1s2_wgrad / k_conv_stem_wgrad (the other weight gradients, on '
                            'v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv1x1_wgrad': ('k_conv1x1_wgrad (weight gradient of the 1x1 stride-1 data convolutions -- the Bottleneck blocks of config 5 -- '
+                              'on v_mfma_f32_32x32x2_f32, NCHW operands as they lie; split-K partial tiles summed by k_conv_wgrad_reduce)', 1.0),
+            'conv1x1_fwd': ('k_conv1x1_gemm (forward of the 1x1 stride-1 data convolutions: one GEMM over the flattened (image, pixel) '
+                            'positions of NCHW, on v_mfma_f32_32x32x2_f32)', 1.0),
+            'conv1x1_dgrad': ('k_conv1x1_gemm (backward-data of the 1x1 stride-1 data convolutions, weights read transposed in place)', 1.0),
             'conv_fwd': ('k_conv_gemm (forward of the data convolutions it owns, on v_mfma_f32_32x32x2_f32)', 1.0),
             'conv_dgrad': ('k_conv_gemm / k_conv_dgrad_s2x4 (backward-data, on v_mfma_f32_32x32x2_f32)', 1.0),
             # the Winograd slots account EXECUTED FLOPs (2 * M * C * 16 per 2x2 output tile = the direct sum's / 2.25)

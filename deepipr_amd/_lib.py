@@ -193,7 +193,7 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum',
-                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad', 'maxpool', 'resample2']
+                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad', 'maxpool', 'resample2', 'conv1x1_fwd', 'conv1x1_dgrad']
 
 
 class ExternalEvent:

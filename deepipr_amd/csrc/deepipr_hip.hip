@@ -3514,8 +3514,8 @@ int launch_res_fwd(const float *x, float *y, const float *gamma, const float *be
 int ranges_stagger(int backward) {
     static int v[2] = {-1, -1};
     if (v[0] < 0) {
-        v[0] = 0;
-        v[1] = 0;
+        v[0] = 2;           // measured on ResNet50's maps at batch 256 (tools/norm_ranges_sweep.sh, profiles/r06e_norm_ranges_sweep.jsonl):
+        v[1] = 2;           // forward 6.02 -> 5.84 ms, backward 8.13 -> 7.65 ms against no stagger; 3 and more lose again
         if (const char *e = getenv("DEEPIPR_BN_STAGGER")) {
             int a = 0, b = 0;
             const int n = sscanf(e, "%d,%d", &a, &b);
@@ -4708,6 +4708,23 @@ int conv_gemm(int slot, const float *wgt, const float *in, float *out, int N, in
     const FwPlan p = plan_conv_any(N, Cin, M, H, W, k, stride, pad);
     if (p.cfg >= 1000) return conv_wino<DGRAD>(p, wgt, in, out, N, Cin, M, H, W, st, what, workspace, workspace_bytes);
     if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "%s: shape outside the kernel (use the library's convolution)", what);
+    if (p.cfg >= 900) {                                                  // 1x1 stride 1: one GEMM over NCHW (deepipr_conv_1x1.inc)
+        if (!aligned16(wgt) || !aligned16(in) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
+        ProfScope prof(DGRAD ? DEEPIPR_K_CONV1X1_DGRAD : DEEPIPR_K_CONV1X1_FWD, st);
+        prof.bytes = 2.0 * M * Cin * static_cast<double>(N) * H * W;     // FLOPs
+        const int total = N * H * W, bm = (p.cfg - 900) / 10, tiles_m = M / (64 * bm);
+#define DEEPIPR_F1(BM, VEC)                                                                                           \
+    DEEPIPR_LAUNCH(prof, (k_conv1x1_gemm<F1Cfg<BM, 2, DGRAD, VEC>>), dim3(p.grid), dim3(256), st, wgt, in, out, M, Cin, H * W, total, tiles_m)
+        switch (p.cfg) {
+            case 910: DEEPIPR_F1(1, 4); break;
+            case 911: DEEPIPR_F1(1, 1); break;
+            case 920: DEEPIPR_F1(2, 4); break;
+            case 921: DEEPIPR_F1(2, 1); break;
+            default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
+        }
+#undef DEEPIPR_F1
+        return check_launch(what);
+    }
     if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))
         return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
     // split K needs its slabs: without a workspace (the entry points of ABI v7) the plain form runs

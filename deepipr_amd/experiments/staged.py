@@ -358,7 +358,10 @@ class StagedStep:
                         # node of a captured graph is where RCCL's watchdog thread died one run in five ("operation not
                         # permitted on an event last recorded in a capturing stream" from its hipEventQuery of the
                         # collective's end event; tools/nccl_flake_probe.sh, profiles/r04_nccl_flake_probe.txt).
+                        tw = time.perf_counter() if tr is not None else 0.0
                         self._events[k].synchronize()
+                        if tr is not None:                  # every wait's length, per stage (bench.py --stage-host-wait-histogram)
+                            tr.setdefault('waits', {}).setdefault(k, []).append(time.perf_counter() - tw)
                         opt.exchange_stages(lo, hi, after=False, overlap=True, packed=True)
                     else:
                         opt.exchange_stages(lo, hi, after=self._events[k], overlap=True, packed=True)

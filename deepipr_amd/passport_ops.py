@@ -1078,6 +1078,8 @@ def _own_policy(n, h, w, k, stride, backward_data=False):
     if backward_data and stride == 2 and (torch.backends.cudnn.deterministic or torch.are_deterministic_algorithms_enabled()):
         return True
     if stride == 1:
+        if k == 1:
+            return OWN_1X1                          # k_conv1x1_gemm against the BLAS library's batched GEMM (tools/conv1x1_bench.py)
         return k == 3 and OWN_S1_MIN_POSITIONS > 0 and n * h * w >= OWN_S1_MIN_POSITIONS
     if stride != 2:
         return False
@@ -1130,6 +1132,9 @@ def _own_wgrad(x_in, w, stride, pad):
 # (deepipr_conv_1x1.inc).  Stride 2 (the projection shortcuts at ImageNet map widths, where deepipr_conv_fwd has no
 # instance): the same GEMMs behind / in front of the pixel gather (deepipr_subsample2 / deepipr_upsample2_zero).
 GEMM_1X1 = os.environ.get('DEEPIPR_GEMM_1X1', '1') != '0'
+# ... and where this library's own NCHW GEMM (deepipr_conv_fwd / _dgrad with k = 1, stride 1: k_conv1x1_gemm) has an instance it
+# takes the forward / backward-data GEMMs instead of the BLAS library (DEEPIPR_OWN_1X1=0: the BLAS library for all of them)
+OWN_1X1 = os.environ.get('DEEPIPR_OWN_1X1', '1') != '0'
 
 
 def _gemm_1x1(x_shape, w, stride, pad, t):
@@ -1156,6 +1161,8 @@ def _conv_fwd(x_in, w, stride, pad, ctx=None):
         if ctx is not None and stride == 2:
             ctx.gathered = xs                          # the weight gradient's operand
         n, ci, h, wd = xs.shape
+        if stride == 2 and OWN_1X1 and kernels.conv_supported(n, ci, w.shape[0], h, wd, 1, 1, 0, 0):
+            return kernels.conv_fwd(xs, w, 1, 0)       # the own GEMM on the gathered pixels
         # bmm with the weight as a stride-0 batch (torch.matmul would fold the batch into the GEMM's rows through a transposed
         # COPY of the activations: 40 ms per ResNet50 step, profiles/r06c_steady_state_r50_matmul_copy.md)
         return torch.bmm(w.view(1, w.shape[0], ci).expand(n, -1, -1), xs.view(n, ci, h * wd)).view(n, w.shape[0], h, wd)
@@ -1168,6 +1175,8 @@ def _conv_dgrad(dconv, x_in, w, stride, pad, pre=None):
     if _gemm_1x1(x_in.shape, w, stride, pad, dconv):
         n, co, oh, ow = dconv.shape
         ci = w.shape[1]
+        if stride == 2 and OWN_1X1 and kernels.conv_supported(n, ci, co, oh, ow, 1, 1, 0, 1):
+            return kernels.upsample2_zero(kernels.conv_dgrad(dconv, w, (n, ci, oh, ow), 1, 0), tuple(x_in.shape))
         dxs = torch.bmm(w.view(1, co, ci).transpose(1, 2).expand(n, -1, -1), dconv.reshape(n, co, oh * ow)).view(n, ci, oh, ow)
         return dxs if stride == 1 else kernels.upsample2_zero(dxs, tuple(x_in.shape))
     return torch.ops.aten.convolution_backward(dconv, x_in, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0],

@@ -92,7 +92,9 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_CONV1X1_WGRAD 31       /* 1x1 stride-1 weight gradient (deepipr_conv_1x1.inc): FLOPs */
 #define DEEPIPR_K_MAXPOOL 32              /* 3x3 stride-2 max-pool forward / backward (bytes) */
 #define DEEPIPR_K_RESAMPLE2 33            /* the stride-2 pixel gather / zero-interleaving scatter around a 1x1 stride-2 convolution (bytes) */
-#define DEEPIPR_PROFILE_KERNELS 34
+#define DEEPIPR_K_CONV1X1_FWD 34          /* 1x1 stride-1 forward / backward-data GEMM over NCHW (deepipr_conv_1x1.inc): FLOPs */
+#define DEEPIPR_K_CONV1X1_DGRAD 35
+#define DEEPIPR_PROFILE_KERNELS 36
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -508,7 +510,9 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
  * Supported (deepipr_conv_supported; direction 0 = forward, 1 = backward-data): Ci, Co multiples of 64;
  *   3x3 pad 1 stride 1 on output maps 4 / 8 / 16 / 32 wide (both directions),
  *   3x3 pad 1 stride 2 and 1x1 pad 0 stride 2 on output maps 4 / 8 / 16 wide (both directions; 3x3 backward-data also 32);
- *   whole row bands: the output height a multiple of 8 / 8 / 4 / 2 (32-, 16-, 8-, 4-wide maps), N a multiple of 4 on 4-wide maps.
+ *   whole row bands: the output height a multiple of 8 / 8 / 4 / 2 (32-, 16-, 8-, 4-wide maps), N a multiple of 4 on 4-wide maps;
+ *   1x1 pad 0 stride 1 on any map (both directions; ABI v11): one GEMM over the flattened (image, pixel) positions, the
+ *   Bottleneck's convolutions (models/resnet_normal.py:30-49); N * H * W * max(Ci, Co) below 2^31.
  * Anything else returns DEEPIPR_EUNSUPPORTED without enqueuing anything: the caller keeps the library's convolution.
  * replaces: aten::convolution / the data half of aten::convolution_backward behind `self.conv(x)`,
  *           models/layers/passportconv2d.py:218 (private twin :215), models/layers/conv2d.py:31 -- for the stride-2

@@ -78,3 +78,45 @@ def test_passport_layer_with_a_1x1_stride2_data_convolution_follows_the_library_
         res[on] = (y.detach(), pas.weight.grad, x.grad)
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+# (N, Ci, Co, H, W): the own NCHW GEMM (k_conv1x1_gemm) -- 128- / 64-channel output tiles either direction, 16-byte and 4-byte
+# activation items (7x7 planes, odd maps), position tiles that cross image boundaries and a ragged last tile
+GEMM_SHAPES = [(3, 64, 256, 56, 56), (2, 256, 64, 56, 56), (5, 128, 512, 28, 28), (3, 1024, 256, 14, 14), (7, 512, 2048, 7, 7),
+               (5, 2048, 512, 7, 7), (1, 64, 64, 7, 7), (3, 64, 128, 5, 9), (2, 192, 64, 6, 10), (33, 64, 64, 2, 2), (256, 512, 128, 7, 7)]
+
+
+@pytest.mark.parametrize('shape', GEMM_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_own_1x1_gemm_forward_and_backward_data_match_the_float64_oracle_and_are_bit_reproducible(shape):
+    from deepipr_amd.passport_ops import kernels as K
+    n, ci, co, h, w = shape
+    x, wt, dy = _rand((n, ci, h, w), 1 + n), _rand((co, ci, 1, 1), 2 + co, 0.05), _rand((n, co, h, w), 3 + ci)
+    assert K.conv_supported(n, ci, co, h, w, 1, 1, 0, 0) and K.conv_supported(n, ci, co, h, w, 1, 1, 0, 1)
+    y = K.conv_fwd(x, wt, 1, 0)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double())
+    assert y.shape == ref.shape and float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(y, K.conv_fwd(x, wt, 1, 0))
+    dx = K.conv_dgrad(dy, wt, tuple(x.shape), 1, 0)
+    dref = torch.nn.functional.conv_transpose2d(dy.double(), wt.double())
+    assert dx.shape == dref.shape and float((dx.double() - dref).abs().max()) <= 1e-5 * float(dref.abs().max())
+    assert torch.equal(dx, K.conv_dgrad(dy, wt, tuple(x.shape), 1, 0))
+
+
+def test_own_1x1_gemm_is_exact_on_small_integers():
+    """Sparse small-integer operands: every output is an exact small sum -- a channel pair taken twice or skipped, a position
+    decoded into the wrong image, a block stored to the wrong channel rows is an exact mismatch."""
+    from deepipr_amd.passport_ops import kernels as K
+    for (n, ci, co, hw) in ((3, 128, 64, 14), (4, 64, 192, 7), (2, 64, 128, 28)):
+        g = torch.Generator(device='cpu').manual_seed(hw)
+        x = (torch.randint(0, 4, (n, ci, hw, hw), generator=g) * (torch.rand(n, ci, hw, hw, generator=g) < 0.2)).float().to(DEV)
+        wt = (torch.randint(-3, 4, (co, ci, 1, 1), generator=g) * (torch.rand(co, ci, 1, 1, generator=g) < 0.3)).float().to(DEV)
+        dy = (torch.randint(0, 4, (n, co, hw, hw), generator=g) * (torch.rand(n, co, hw, hw, generator=g) < 0.2)).float().to(DEV)
+        assert torch.equal(K.conv_fwd(x, wt, 1, 0).double(), torch.nn.functional.conv2d(x.double(), wt.double()))
+        assert torch.equal(K.conv_dgrad(dy, wt, tuple(x.shape), 1, 0).double(),
+                           torch.nn.functional.conv_transpose2d(dy.double(), wt.double()))
+
+
+def test_1x1_shapes_outside_the_gemm_kernel_keep_the_blas_route():
+    from deepipr_amd.passport_ops import kernels as K
+    assert not K.conv_supported(4, 32, 64, 8, 8, 1, 1, 0, 0) and not K.conv_supported(4, 64, 96, 8, 8, 1, 1, 0, 1)
+    assert K.conv_fwd(_rand((4, 32, 8, 8), 1), _rand((64, 32, 1, 1), 2), 1, 0) is None

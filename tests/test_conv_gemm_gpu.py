@@ -124,7 +124,7 @@ def test_one_hot_operands_are_exact(K, k, st):
     assert torch.equal(y.double(), ry) and torch.equal(dx.double(), rdx)
 
 
-@pytest.mark.parametrize('case', [dict(ci=3, co=64), dict(ci=64, co=96), dict(h=14), dict(k=5, pad=2), dict(k=1, pad=0, st=1),
+@pytest.mark.parametrize('case', [dict(ci=3, co=64), dict(ci=64, co=96), dict(h=14), dict(k=5, pad=2), dict(k=1, pad=0, st=1, ci=32), dict(k=1, pad=1, st=1),
                                   dict(h=64, st=2), dict(n=3, h=4), dict(k=3, pad=0)])
 def test_shapes_outside_the_kernels_are_refused(K, case):
     n, ci, co, h = case.get('n', 4), case.get('ci', 64), case.get('co', 64), case.get('h', 8)

@@ -47,7 +47,7 @@ def main():
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda:0')
-    out, tot, tot_lib = [], 0.0, 0.0
+    out, tot, tot_lib, fd = [], 0.0, 0.0, [0.0, 0.0]
     for ci, co, hw, count in SHAPES:
         n = args.batch
         g = torch.Generator(device='cpu').manual_seed(ci + hw)
@@ -77,9 +77,22 @@ def main():
             tl = timeit(lib, args.reps)
             rec.update({'us_library': round(tl, 1), 'TFLOPs_library': round(flops / tl / 1e6, 1)})
             tot_lib += count * tl
+        # forward / backward-data: this library's NCHW GEMM (k_conv1x1_gemm) against the BLAS library's batched GEMM (the route
+        # passport_ops._conv_fwd / _conv_dgrad take without it)
+        fwd_own = lambda: K.conv_fwd(x, w, 1, 0)
+        dg_own = lambda: K.conv_dgrad(dy, w, tuple(x.shape), 1, 0)
+        fwd_blas = lambda: torch.bmm(w.view(1, co, ci).expand(n, -1, -1), x.view(n, ci, hw * hw))
+        dg_blas = lambda: torch.bmm(w.view(1, co, ci).transpose(1, 2).expand(n, -1, -1), dy.view(n, co, hw * hw))
+        if fwd_own() is not None:
+            tf, tb, tfb, tbb = timeit(fwd_own, args.reps), timeit(dg_own, args.reps), timeit(fwd_blas, args.reps), timeit(dg_blas, args.reps)
+            rec.update({'fwd_us': round(tf, 1), 'fwd_TFLOPs': round(flops / tf / 1e6, 1), 'fwd_us_blas': round(tfb, 1),
+                        'dgrad_us': round(tb, 1), 'dgrad_TFLOPs': round(flops / tb / 1e6, 1), 'dgrad_us_blas': round(tbb, 1)})
+            fd[0] += count * (tf + tb)
+            fd[1] += count * (tfb + tbb)
         print(json.dumps(rec), flush=True)
         out.append(rec)
-    summary = {'summary': 'all 33 launches of a ResNet50 step', 'ms': round(tot / 1e3, 2), 'ms_library': round(tot_lib / 1e3, 2)}
+    summary = {'summary': 'all 33 launches of a ResNet50 step', 'ms': round(tot / 1e3, 2), 'ms_library': round(tot_lib / 1e3, 2),
+               'fwd_plus_dgrad_ms': round(fd[0] / 1e3, 2), 'fwd_plus_dgrad_ms_blas': round(fd[1] / 1e3, 2)}
     print(json.dumps(summary), flush=True)
     out.append(summary)
     if args.json:
