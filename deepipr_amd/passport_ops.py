@@ -1057,10 +1057,14 @@ def _own_ok(t, w):
 
 
 # auto: a stride-2 3x3 convolution goes to the own forward / backward-data kernels when it has at least this many output
-# positions (N * OH * OW); below that (ResNet18's layer4.0 at batch <= 128, layer3.0 at batch <= 32) the 64 x 64-tile kernels
-# leave CUs idle and the vendor library, shims included, is as fast or faster (tools/conv_bench.py at batch 128 and 32,
-# profiles/r04_conv_bench*.json).  The 1x1 stride-2 shortcuts always win (8-21 us against 26-46).
-OWN_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_MIN_POSITIONS', 4096))
+# positions (N * OH * OW); below that (ResNet18's layer3.0 at batch <= 32, layer4.0 at batch < 128) the 64 x 64-tile kernels
+# leave CUs idle and the vendor library, shims included, is faster (tools/conv_bench.py at batch 128 and 32,
+# profiles/r04_conv_bench*.json).  At exactly 2 048 positions (layer4.0 of config R, the first passport layer's own data
+# convolution) the two are at par -- 168 us against 164 with the vendor library's five layout transposes and zero fill -- and
+# the own kernels take it (round 6): no vendor convolution and no layout shim is left in the config-R step behind the stem, and
+# the step's last bits no longer depend on the vendor library's solver choice.  The 1x1 stride-2 shortcuts always win (8-21 us
+# against 26-46).
+OWN_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_MIN_POSITIONS', 2048))
 # ... and a stride-1 3x3 convolution from this many output positions up (ResNet18 at batch 128: layer1 and layer2, where the
 # direct kernel runs 78-82 us against Winograd's 88; 0 = never)
 OWN_S1_MIN_POSITIONS = int(os.environ.get('DEEPIPR_OWN_CONV_S1_MIN_POSITIONS', 32768))

@@ -137,3 +137,38 @@ def test_pre_transformed_winograd_stub_of_integration_md_runs_on_the_gpu():
         ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                   [True, False, False])[0]
         assert float((dx.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_section_e_imagenet_stub_runs_on_the_gpu():
+    """INTEGRATION.md section E, extracted and executed: the reference-side `Conv1x1MI355X` (1x1 convolutions of the Bottleneck,
+    stride 1 and 2, all three directions through the C ABI) against F.conv2d in float64 -- 1e-5 of scale -- and
+    `MaxPool3x3s2MI355X` against F.max_pool2d -- bit for bit, forward and backward."""
+    from deepipr_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    code = next(b for b in blocks if b.lstrip().startswith('# models/layers/_deepipr_imagenet.py'))
+    ns = {}
+    exec(compile(code.replace('/path/to/libdeepipr_hip.so', _lib.LIB_PATH), 'INTEGRATION.md#E', 'exec'), ns)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(13)
+    for n, ci, co, h, st in ((4, 64, 256, 56, 1), (3, 1024, 256, 14, 1), (5, 512, 2048, 7, 1), (4, 256, 512, 56, 2), (3, 1024, 2048, 14, 2)):
+        x = torch.randn(n, ci, h, h, generator=g).to(dev).requires_grad_(True)
+        w = (0.05 * torch.randn(co, ci, 1, 1, generator=g)).to(dev).requires_grad_(True)
+        cot = torch.randn(n, co, h // st, h // st, generator=g).to(dev)
+        y = ns['Conv1x1MI355X'].apply(x, w, st)
+        (y * cot).sum().backward()
+        x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        y64 = torch.nn.functional.conv2d(x64, w64, None, st, 0)
+        (y64 * cot.double()).sum().backward()
+        for name, a, ref in (('y', y.detach(), y64.detach()), ('dx', x.grad, x64.grad), ('dW', w.grad, w64.grad)):
+            err = float((a.double() - ref).abs().max()) / max(1e-12, float(ref.abs().max()))
+            assert err <= 1e-5, (n, ci, co, h, st, name, err)
+    for shape in ((2, 64, 112, 112), (3, 5, 7, 9)):
+        x = torch.relu(torch.randn(shape, generator=g)).to(dev).requires_grad_(True)      # the stem's input: a ReLU output, many ties
+        x2 = x.detach().clone().requires_grad_(True)
+        y = ns['MaxPool3x3s2MI355X'].apply(x)
+        y2 = torch.nn.functional.max_pool2d(x2, 3, 2, 1)
+        cot = torch.randn(tuple(y2.shape), generator=g).to(dev)
+        y.backward(cot)
+        y2.backward(cot)
+        assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
