@@ -39,6 +39,7 @@ from deepipr_amd.models.resnet_passport import ResNet18Passport                 
 from deepipr_amd.models.resnet_passport_private import ResNet18Private             # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+HBM_ACHIEVABLE_GBS = 6290.0      # ... the rate a large copy sustains (same guide)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16), 16x the fp32 one
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32, = the vector rate)
 # algorithmic bytes per activation element are accounted by the library per timed
@@ -902,7 +903,17 @@ def main():
             tot_ms = sum(prof_scope[k][0] for k in ps)
             tot_b = sum(prof_scope[k][2] for k in ps)
             gbps = tot_b / (tot_ms * 1e-3) / 1e9
+            # What the SIZE allows: no kernel of this step, however little it does, completes faster than the
+            # shortest ones of this very run (one-workgroup finishers: launch + one memory round trip).  A launch that moves B bytes
+            # cannot beat floor + B / (the copy rate the chip sustains): the fraction of the 8 TB/s peak that bound leaves
+            floor_us = min(v['avg_us'] for v in kern.values() if v.get('launches_per_step'))
+            ceil_b = sum(v['bytes_per_launch'] * v['launches_per_step'] for v in ps.values())
+            ceil_us = sum((floor_us + v['bytes_per_launch'] / (HBM_ACHIEVABLE_GBS * 1e3)) * v['launches_per_step'] for v in ps.values())
             out['roofline_passport'] = {
+                'launch_floor_us': round(floor_us, 2),
+                'frac_ceiling_at_this_size': round(ceil_b / (ceil_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                'ceiling_note': 'shortest kernel of this run (launch floor) + bytes at the %.1f TB/s a copy sustains, per launch: '
+                                'the fraction of the HBM peak a launch of this size can reach at all' % (HBM_ACHIEVABLE_GBS / 1e3),
                 'bound': 'hbm', 'kernel': 'the norm + passport affine + ReLU launches of the %d passport layer calls only '
                 '(forward and backward together)' % len(elems),
                 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBS, 4),

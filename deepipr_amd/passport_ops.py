@@ -1049,6 +1049,12 @@ def prefer_own_kernels():
     if not _OWN_CONV_FROM_ENV and OWN_CONV == 'auto':
         OWN_CONV = 'all'
         OWN_WGRAD = os.environ.get('DEEPIPR_OWN_WGRAD', '1') != '0'
+    # ... and what this library has no instance for runs on the vendor library's DETERMINISTIC solvers (round 6: the V3 shard's 66
+    # images on 4-wide maps are outside the stride-2 kernels -- a multiple of four images there -- and the vendor backward-data
+    # that took them accumulates with atomics: a rank did not even agree with ITSELF bit for bit,
+    # profiles/r06_nrank_rehearsal.jsonl: same_rank_repeat_agrees false).  DEEPIPR_VENDOR_DETERMINISTIC=0 leaves the choice alone.
+    if os.environ.get('DEEPIPR_VENDOR_DETERMINISTIC', '1') != '0':
+        torch.backends.cudnn.deterministic = True
     return OWN_CONV
 
 
