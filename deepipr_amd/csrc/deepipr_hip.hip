@@ -4709,20 +4709,41 @@ int conv_gemm(int slot, const float *wgt, const float *in, float *out, int N, in
     if (p.cfg >= 1000) return conv_wino<DGRAD>(p, wgt, in, out, N, Cin, M, H, W, st, what, workspace, workspace_bytes);
     if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "%s: shape outside the kernel (use the library's convolution)", what);
     if (p.cfg >= 900) {                                                  // 1x1 stride 1: one GEMM over NCHW (deepipr_conv_1x1.inc)
-        if (!aligned16(wgt) || !aligned16(in) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
-        ProfScope prof(DGRAD ? DEEPIPR_K_CONV1X1_DGRAD : DEEPIPR_K_CONV1X1_FWD, st);
-        prof.bytes = 2.0 * M * Cin * static_cast<double>(N) * H * W;     // FLOPs
+        if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))
+            return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
         const int total = N * H * W, bm = (p.cfg - 900) / 10, tiles_m = M / (64 * bm);
+        // the stream-K tail needs its workspace: without one (the workspace-free entry points) every tile is a whole tile
+        const bool tail = p.splits > 1 && workspace && workspace_bytes >= 2 * p.slab * sizeof(float);
+        const int tail_tiles = tail ? p.bands : 0, full_tiles = p.grid - tail_tiles;
+        const int tail_wgs = tail ? static_cast<int>(p.slab / (64 * bm * 128)) : 0;
+        float *ws1 = static_cast<float *>(workspace);
+        {
+            ProfScope prof(DGRAD ? DEEPIPR_K_CONV1X1_DGRAD : DEEPIPR_K_CONV1X1_FWD, st);
+            prof.bytes = 2.0 * M * Cin * static_cast<double>(N) * H * W;     // FLOPs
 #define DEEPIPR_F1(BM, VEC)                                                                                           \
-    DEEPIPR_LAUNCH(prof, (k_conv1x1_gemm<F1Cfg<BM, 2, DGRAD, VEC>>), dim3(p.grid), dim3(256), st, wgt, in, out, M, Cin, H * W, total, tiles_m)
-        switch (p.cfg) {
-            case 910: DEEPIPR_F1(1, 4); break;
-            case 911: DEEPIPR_F1(1, 1); break;
-            case 920: DEEPIPR_F1(2, 4); break;
-            case 921: DEEPIPR_F1(2, 1); break;
-            default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
-        }
+    DEEPIPR_LAUNCH(prof, (k_conv1x1_gemm<F1Cfg<BM, 2, DGRAD, VEC>>), dim3(full_tiles + tail_wgs), dim3(256), st, wgt, in, out, M, Cin, \
+                   H * W, total, tiles_m, full_tiles, tail_tiles, tail_wgs, ws1)
+            switch (p.cfg) {
+                case 910: DEEPIPR_F1(1, 4); break;
+                case 911: DEEPIPR_F1(1, 1); break;
+                case 920: DEEPIPR_F1(2, 4); break;
+                case 921: DEEPIPR_F1(2, 1); break;
+                default: return fail(DEEPIPR_EUNSUPPORTED, "%s: no instance", what);
+            }
 #undef DEEPIPR_F1
+        }
+        if (tail) {
+            ProfScope prof(DEEPIPR_K_CONV_SPLIT_SUM, st);
+            prof.bytes = 4.0 * (64.0 * bm * 128) * (tail_wgs + 2.0 * tail_tiles);
+            const dim3 grid(tail_tiles * (64 * bm * 128 / 4 / 256));
+            const bool v4 = (H * W) % 4 == 0;
+#define DEEPIPR_F1S(TM, V4)                                                                                           \
+    DEEPIPR_LAUNCH(prof, (k_conv1x1_tail_sum<TM, 128, V4>), grid, dim3(256), st, ws1, out, M, H * W, total, tiles_m, full_tiles,  \
+                   tail_tiles, tail_wgs, p.cps)
+            if (bm == 2) { if (v4) DEEPIPR_F1S(128, true); else DEEPIPR_F1S(128, false); }
+            else { if (v4) DEEPIPR_F1S(64, true); else DEEPIPR_F1S(64, false); }
+#undef DEEPIPR_F1S
+        }
         return check_launch(what);
     }
     if (!aligned16(wgt) || !aligned16(in) || !aligned16(out) || !aligned16(workspace))

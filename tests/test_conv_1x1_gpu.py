@@ -120,3 +120,33 @@ def test_1x1_shapes_outside_the_gemm_kernel_keep_the_blas_route():
     from deepipr_amd.passport_ops import kernels as K
     assert not K.conv_supported(4, 32, 64, 8, 8, 1, 1, 0, 0) and not K.conv_supported(4, 64, 96, 8, 8, 1, 1, 0, 1)
     assert K.conv_fwd(_rand((4, 32, 8, 8), 1), _rand((64, 32, 1, 1), 2), 1, 0) is None
+
+
+def test_stream_k_tail_of_the_1x1_gemm_is_correct_exact_on_integers_and_reproducible(tmp_path):
+    """k_conv1x1_gemm cuts the tiles of the last, partial round of workgroup slots along K (stream-K: partial tiles in a workspace,
+    summed in workgroup order by k_conv1x1_tail_sum).  Forced on for every shape whose tile count is not a multiple of the slots
+    (DEEPIPR_CONV1X1_STREAMK=2) and switched off (=0), in a process each: both within 1e-5 of scale of float64 ATen, both exact on
+    small integers, both bit-reproducible; the forced runs really took the tail (a non-zero workspace) and -- a different summation
+    order -- agree with the plain runs to rounding."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for mode in ('2', '0'):
+        out = str(tmp_path / ('streamk%s.npz' % mode))
+        subprocess.run([sys.executable, os.path.join(here, 'conv1x1_streamk_case.py'), out], check=True, timeout=600,
+                       env=dict(os.environ, DEEPIPR_CONV1X1_STREAMK=mode))
+        got[mode] = np.load(out)
+    from tests.conv1x1_streamk_case import SHAPES
+    took_tail = 0
+    for i in range(len(SHAPES)):
+        for mode in ('2', '0'):
+            d = got[mode]
+            assert float(d['err_y_%d' % i]) <= 1e-5 and float(d['err_dx_%d' % i]) <= 1e-5, (SHAPES[i], mode)
+            assert bool(d['exact_%d' % i]) and bool(d['repeat_%d' % i]), (SHAPES[i], mode)
+        assert tuple(got['0']['ws_%d' % i]) == (0, 0)
+        took_tail += int(got['2']['ws_%d' % i][0] > 0) + int(got['2']['ws_%d' % i][1] > 0)
+        a, b = got['2']['y_%d' % i], got['0']['y_%d' % i]
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    assert took_tail >= len(SHAPES)                            # (a tile count that happens to be a multiple of the slots has no tail)

@@ -19,6 +19,8 @@ from deepipr_amd.passport_ops import kernels as K              # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(N, 64, 32, 32), (N, 128, 16, 16), (N, 256, 8, 8), (N, 512, 4, 4), (4 * N, 512, 8, 8)]
+if os.environ.get('DEEPIPR_TRACE_SHAPES'):       # "256,256,56,56;256,64,56,56": maps beyond the register file -- the stamps of a ranges
+    SHAPES = [tuple(int(v) for v in sh.split(',')) for sh in os.environ['DEEPIPR_TRACE_SHAPES'].split(';')]    # launch are its LAST range's
 dev = torch.device('cuda:0')
 TICK_US = 0.01                                                  # wall_clock64(): 100 MHz
 
