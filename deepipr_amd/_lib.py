@@ -122,8 +122,8 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_wino_trace': (_int, [_vp]),
 }
 ABI_VERSION = 11
-SYNC_WORDS = 2 * (256 * 30 * 4 + 4096) + 16     # DEEPIPR_SYNC_WORDS
-SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 4096)   # DEEPIPR_SYNC_TIMEOUT_WORD
+SYNC_WORDS = 2 * (256 * 30 * 4 + 4096 + 63 * 2048) + 16     # DEEPIPR_SYNC_WORDS
+SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 4096 + 63 * 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
 
 GEMV_MAX_LAYERS = 16                    # DEEPIPR_GEMV_MAX_LAYERS

@@ -1501,7 +1501,13 @@ __global__ __launch_bounds__(kThreads) void k_passport_bn_bwd_finish(
 // most 256 / S channels), so the channel ranges of one layer reuse the slots.
 constexpr int kXchChannels = 256;                  // channels are split only when C < CUs, i.e. C <= 255
 constexpr int kXchMaxSlices = 64;                  // 4 granules per slice: up to 256 granules, four per lane of wave 0
-constexpr int kXchGranules = kXchChannels * (2 + 4 + 8 + 16) * 4 + 2 * 2048;      // S = 32 / 64: two slot sets of 256 / S channels each
+constexpr int kXchPow2Granules = kXchChannels * (2 + 4 + 8 + 16) * 4 + 2 * 2048;     // the regions of S = 2 .. 16 (+ two retired ones)
+// ... and ONE REGION PER SLICE COUNT 2 .. 64 for the layers that run as channel ranges (plan_resident: any slice count there, two
+// slot sets of 256 / S channels each = at most 2 048 granules): a slice derives the exchange's tag from its OWN slot's history, so
+// launches with different S must never share slots (the first round-6 attempt let S = 18 use the region of 32: the partners
+// computed different tags and every wait expired)
+constexpr int kXchAnyRegion = 2048;
+constexpr int kXchGranules = kXchPow2Granules + 63 * kXchAnyRegion;
 constexpr int kSyncTimeoutWord = 2 * kXchGranules;
 static_assert(kSyncTimeoutWord == DEEPIPR_SYNC_TIMEOUT_WORD && kSyncTimeoutWord + 16 == DEEPIPR_SYNC_WORDS, "header out of step");
 constexpr unsigned kSpinLimit = 1u << 22;          // x s_sleep(2) + one poll: a few seconds
@@ -1514,6 +1520,7 @@ struct ResPlan {
     int c_off;            // first channel of this launch (channel-range passes of a map too large for one pass)
     int cpp, passes;      // host side: channels per pass, number of passes (1: the whole layer in one launch)
     int stagger;          // ranges kernels: odd channel groups start this many s_sleep(127) late (phases of neighbours interleave)
+    int xoff;             // granule offset of this launch's exchange region (xch_region)
     FastDiv gqdiv;
 #ifdef DEEPIPR_TEST_HOOKS
     // Measurement / test build only (`make trace`: libdeepipr_hip_trace.so; the production library has none of this):
@@ -1653,15 +1660,17 @@ __device__ __forceinline__ unsigned long long xch_load(const unsigned long long 
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load ... sc1: bypasses L1
 }
 
-__device__ __forceinline__ int xch_region(int S) {
-    if (S <= 16) return kXchChannels * (S - 2) * 4;                         // 2 + 4 + ... + S/2 = S - 2
-    return kXchChannels * 30 * 4 + (S == 32 ? 0 : 2048);
+// granule offset of the exchange region of a launch (host side: ResPlan::xoff).  Power-of-two S up to 16 of the one-launch
+// forms: a region of 256 channel slots; the channel-range form (any S): the region of exactly this S.
+inline int xch_region(int S, bool ranges) {
+    if (ranges) return kXchPow2Granules + (S - 2) * kXchAnyRegion;
+    return kXchChannels * (S - 2) * 4;                                      // 2 + 4 + ... + S/2 = S - 2   (S = 2, 4, 8, 16)
 }
 
 // Called by every thread at kernel entry (only wave 0 needs it; one L2 round trip hidden behind the bulk loads).
-__device__ __forceinline__ ResXch res_xch_begin(unsigned *sync, int c, int s, int S) {
+__device__ __forceinline__ ResXch res_xch_begin(unsigned *sync, int xoff, int c, int s, int S) {
     ResXch x;
-    x.gran = reinterpret_cast<unsigned long long *>(sync) + xch_region(S) + static_cast<size_t>(c) * S * 4;
+    x.gran = reinterpret_cast<unsigned long long *>(sync) + xoff + static_cast<size_t>(c) * S * 4;
     x.expect = 0;
     if (threadIdx.x < kWave) x.expect = static_cast<unsigned>(xch_load(x.gran + s * 4) >> 32) + 1u;
     return x;
@@ -1915,7 +1924,7 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd(
     int cb, s;
     res_block_coords(pl, cb, s);
     ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);              // slot = the channel's index within this launch
+    if (pl.S > 1) xc = res_xch_begin(sync, pl.xoff, cb, s, pl.S);              // slot = the channel's index within this launch
     bn_res_fwd_range<T, F4>(x, y, gamma, beta, relu, N, C, pl, f, sync, residual, red, xch, cb, s, pl.c_off, xc, true);
 }
 
@@ -1941,7 +1950,7 @@ __global__ __launch_bounds__(T) void k_bn_res_fwd_ranges(
         const int c_off = r * pl.cpp;
         if (cb * pl.G >= C - c_off) break;                             // the last range may be short (whole workgroups leave)
         // this range's slot set; its tag is read afresh (this workgroup's own granule of range r - 2: old + 1 again)
-        const ResXch xc = res_xch_begin(sync, cb + (r & 1) * pl.cpp, s, pl.S);
+        const ResXch xc = res_xch_begin(sync, pl.xoff, cb + (r & 1) * pl.cpp, s, pl.S);
         bn_res_fwd_range<T, F4, true>(x, y, gamma, beta, relu, N, C, pl, f, sync, residual, red, xch, cb, s, c_off, xc, r == 0);
     }
 }
@@ -2069,7 +2078,7 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd(
     int cb, s;
     res_block_coords(pl, cb, s);
     ResXch xc{};
-    if (pl.S > 1) xc = res_xch_begin(sync, cb, s, pl.S);
+    if (pl.S > 1) xc = res_xch_begin(sync, pl.xoff, cb, s, pl.S);
     bn_res_bwd_range<T, F4>(dy, x, tbl, dx, relu, N, C, pl, sync, a, red, xch, cb, s, pl.c_off, xc);
 }
 
@@ -2087,7 +2096,7 @@ __global__ __launch_bounds__(T) void k_bn_res_bwd_ranges(
     for (int r = 0; r < pl.passes; ++r) {
         const int c_off = r * pl.cpp;
         if (cb * pl.G >= C - c_off) break;
-        const ResXch xc = res_xch_begin(sync, cb + (r & 1) * pl.cpp, s, pl.S);
+        const ResXch xc = res_xch_begin(sync, pl.xoff, cb + (r & 1) * pl.cpp, s, pl.S);
         bn_res_bwd_range<T, F4, true>(dy, x, tbl, dx, relu, N, C, pl, sync, a, red, xch, cb, s, c_off, xc);
     }
 }
@@ -2134,8 +2143,8 @@ __global__ __launch_bounds__(T) void k_bn_dual_fwd(
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
     ResXch xca{}, xcb{};
     if (pl.S > 1) {
-        xca = res_xch_begin(sync, cb, s, pl.S);
-        xcb = res_xch_begin(sync, cb + C, s, pl.S);
+        xca = res_xch_begin(sync, pl.xoff, cb, s, pl.S);
+        xcb = res_xch_begin(sync, pl.xoff, cb + C, s, pl.S);
     }
     const int c_mine = c0 + c_local;
     const float ga = gamma_a[c_mine], ba = beta_a[c_mine], gb = d.gamma_b[c_mine], bb = d.beta_b[c_mine];
@@ -2279,8 +2288,8 @@ __global__ __launch_bounds__(T) void k_bn_dual_bwd(
     const int c_local = (pl.G == 1) ? 0 : (t % pl.gq) / pl.q4;
     ResXch xca{}, xcb{};
     if (pl.S > 1) {
-        xca = res_xch_begin(sync, cb, s, pl.S);
-        xcb = res_xch_begin(sync, cb + C, s, pl.S);
+        xca = res_xch_begin(sync, pl.xoff, cb, s, pl.S);
+        xcb = res_xch_begin(sync, pl.xoff, cb + C, s, pl.S);
     }
     const float4 cha = *reinterpret_cast<const float4 *>(tbl_a + static_cast<size_t>(c0 + c_local) * kTbl);
     const float4 chb = *reinterpret_cast<const float4 *>(a.tbl_b + static_cast<size_t>(c0 + c_local) * kTbl);
@@ -3432,7 +3441,9 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
     pl.c_off = 0;
     pl.cpp = C;
     pl.passes = 1;
+    bool range_mode = false;                     // the slice count comes from the channel-range search (any integer: its own region)
     if (pl.F4 == 0) {
+        range_mode = true;
         // The layer does not fit the register file at once (ImageNet-size maps: [128, 64, 112, 112] is 411 MB against
         // 67 MB of registers a forward / 33 MB per tensor a backward launch can hold).  Channel-range PASSES: a launch
         // takes as many channels as fill the chip once each is split over S workgroups, S the smallest power of two for
@@ -3445,7 +3456,23 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
         // (at most 12 float4 per thread: the 16-unit forward instance has no register to spare for the loop over ranges of
         // k_bn_res_fwd_ranges -- 24 spilled -- and a range is a loop iteration now, not a launch)
         const int pass_f4 = max_f4 > 12 ? 12 : max_f4;
-        for (int Sp = 2; Sp <= kXchMaxSlices && Sp <= N && Sp <= lim; Sp *= 2) {
+        // The slice count that FILLS a workgroup's registers -- any integer from 2 to 64, not only a power of two (round 6: the
+        // exchange costs 2.4 - 4.4 us of a range's ~15 whatever the range holds, tools/res_trace.py on ResNet50's maps,
+        // profiles/r06k_res_trace_r50.log: 784-float4 planes at 12 units per thread take 15 samples per slice -- 18 slices, 19
+        // ranges of 14 channels -- where the next power of two took 8 samples, 32 slices and 32 ranges of 8).  The exchange's
+        // slot regions are per slice count (xch_region).
+        // Measured on ResNet50's maps at batch 256 (tools/norm_ranges_bench.py, profiles/r06m_norm_slices.jsonl): forward 5.78 ->
+        // 5.28 ms with the filling slice count; backward (8 units per thread: the power of two already fills 77 % of them)
+        // 7.38 -> 7.71 ms -- it keeps the power of two.  DEEPIPR_BN_POW2_SLICES = 1 / 0 forces one rule for both directions.
+        static const int force_pow2 = getenv("DEEPIPR_BN_POW2_SLICES") ? atoi(getenv("DEEPIPR_BN_POW2_SLICES")) : -1;
+        const bool pow2_only = force_pow2 >= 0 ? force_pow2 != 0 : max_f4 <= 8;
+        const long long cap = static_cast<long long>(pass_f4) * 1024 / pl.q4;       // samples a workgroup can hold
+        int Sp = cap >= 1 ? static_cast<int>((N + cap - 1) / cap) : kXchMaxSlices + 1;
+        if (Sp < 2) Sp = 2;
+        if (pow2_only)
+            for (int p2 = 2; ; p2 *= 2)
+                if (p2 >= Sp) { Sp = p2; break; }
+        if (Sp <= kXchMaxSlices && Sp <= N && Sp <= lim) {
             const long long nps = (N + Sp - 1) / Sp;
             const long long nd = (nps * pl.q4 + 1023) / 1024;
             int f4 = 0;
@@ -3454,20 +3481,21 @@ bool plan_resident(int N, int C, int P, int max_f4, bool can_sync, ResPlan *out)
                     f4 = f;
                     break;
                 }
-            if (!f4) continue;
-            pl.S = Sp;
-            pl.nps = static_cast<int>(nps);
-            pl.T = 1024;
-            pl.F4 = f4;
-            pl.cpp = lim / Sp < C ? lim / Sp : C;
-            pl.passes = (C + pl.cpp - 1) / pl.cpp;
-            pl.blocks = pl.cpp * Sp;
-            found = true;
-            break;
+            if (f4) {
+                pl.S = Sp;
+                pl.nps = static_cast<int>(nps);
+                pl.T = 1024;
+                pl.F4 = f4;
+                pl.cpp = lim / Sp < C ? lim / Sp : C;
+                pl.passes = (C + pl.cpp - 1) / pl.cpp;
+                pl.blocks = pl.cpp * Sp;
+                found = true;
+            }
         }
         if (!found) return false;
     }
     pl.gqdiv = make_fastdiv(static_cast<unsigned>(pl.gq));
+    pl.xoff = pl.S > 1 ? xch_region(pl.S, range_mode) : 0;
 #ifdef DEEPIPR_TEST_HOOKS
     pl.spin = static_cast<unsigned>(g_tune.spin.load(std::memory_order_relaxed));
     pl.drop = g_tune.drop.load(std::memory_order_relaxed);
@@ -3529,7 +3557,7 @@ int ranges_stagger(int backward) {
 // all `pl.passes` channel ranges of the layer in one launch (k_bn_res_fwd_ranges); false: no instance (the caller loops)
 bool launch_res_fwd_ranges(const float *x, float *y, const float *gamma, const float *beta, int relu, int N, int C,
                            const ResPlan &pl, const BnFinishArgs &f, unsigned *sync, const float *residual, hipStream_t st) {
-    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp > kXchChannels || (pl.F4 != 12 && pl.F4 != 8)) return false;
+    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp * pl.S > 512 || (pl.F4 != 12 && pl.F4 != 8 && pl.F4 != 6)) return false;
     ProfScope prof(DEEPIPR_K_BN_RES_FWD, st);
     prof.bytes = (residual ? 12.0 : 8.0) * static_cast<double>(N) * C * pl.q4 * 4;
     const dim3 grid(pl.cpp * pl.S);
@@ -3538,7 +3566,8 @@ bool launch_res_fwd_ranges(const float *x, float *y, const float *gamma, const f
     ResPlan q = pl;
     q.stagger = ranges_stagger(0);
     if (pl.F4 == 12) DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 12>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
-    else DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 8>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
+    else if (pl.F4 == 8) DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 8>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
+    else DEEPIPR_LAUNCH(prof, (k_bn_res_fwd_ranges<1024, 6>), grid, dim3(1024), st, x4, y4, gamma, beta, relu, N, C, q, f, sync, r4);
     return true;
 }
 
@@ -3560,7 +3589,7 @@ int launch_res_bwd(const float *dy, const float *x, const float *tbl, float *dx,
 
 bool launch_res_bwd_ranges(const float *dy, const float *x, const float *tbl, float *dx, int relu, int N, int C,
                            const ResPlan &pl, unsigned *sync, const ResBwdArgs &a, hipStream_t st) {
-    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp > kXchChannels || (pl.F4 != 6 && pl.F4 != 8)) return false;
+    if (pl.passes < 2 || pl.T != 1024 || pl.G != 1 || pl.S < 2 || 2 * pl.cpp * pl.S > 512 || (pl.F4 != 6 && pl.F4 != 8 && pl.F4 != 4)) return false;
     ProfScope prof(DEEPIPR_K_BN_RES_BWD, st);
     prof.bytes = (a.tail_out ? (a.dy2 ? 24.0 : 20.0) : (a.dy2 ? 16.0 : 12.0)) * static_cast<double>(N) * C * pl.q4 * 4;
     const dim3 grid(pl.cpp * pl.S);
@@ -3569,7 +3598,8 @@ bool launch_res_bwd_ranges(const float *dy, const float *x, const float *tbl, fl
     ResPlan q = pl;
     q.stagger = ranges_stagger(1);
     if (pl.F4 == 6) DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 6>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
-    else DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 8>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
+    else if (pl.F4 == 8) DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 8>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
+    else DEEPIPR_LAUNCH(prof, (k_bn_res_bwd_ranges<1024, 4>), grid, dim3(1024), st, d4, x4, tbl, o4, relu, N, C, q, sync, a);
     return true;
 }
 

@@ -269,8 +269,8 @@ int deepipr_passport_bwd(const float *dy, const float *xhat, const float *gamma,
  * kernel (16 B/element) instead of by a separate add pass.  deepipr_passport_bn_resident(N, C, HW, have_sync) -> bit 0: forward, bit 1: backward take
  * the single-pass form for this shape; with a residual / tail_out outside it the entry points return
  * DEEPIPR_EUNSUPPORTED and enqueue nothing. */
-#define DEEPIPR_SYNC_WORDS (2 * (256 * 30 * 4 + 4096) + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, 2 x 2048 for 32 / 64 slices (two slot sets: ABI v11), + flags */
-#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * (256 * 30 * 4 + 4096))
+#define DEEPIPR_SYNC_WORDS (2 * (256 * 30 * 4 + 4096 + 63 * 2048) + 16)   /* 8-byte granules: 256 channels x (2+4+8+16) slices x 4, two retired regions, one region of 2 048 per slice count 2 .. 64 of the channel-range form (ABI v11), + flags: 1.3 MB */
+#define DEEPIPR_SYNC_TIMEOUT_WORD (2 * (256 * 30 * 4 + 4096 + 63 * 2048))
 int deepipr_set_resident(int mode);
 #ifdef DEEPIPR_TEST_HOOKS
 /* MEASUREMENT / TEST BUILD ONLY (libdeepipr_hip_trace.so, `make -C deepipr_amd/csrc trace`): the production library
