@@ -9,6 +9,17 @@
 
 #define DIPR_HIDDEN __attribute__((visibility("hidden")))
 
+// Workgroup b of a launch runs on XCD b % 8 (observed dispatch order; used for speed only), each XCD with an L2 of its own.  Tiles
+// that share an operand are neighbours in the tile index: taken as they come they land on eight DIFFERENT XCDs and each fetches
+// the shared operand through the fabric.  The remap makes the workgroups of ONE XCD walk a contiguous eighth of the index space:
+// neighbours meet in one L2.  (n not a multiple of 8: the last n % 8 indices stay put.)
+__device__ __forceinline__ int dipr_xcd_contiguous(int b, int n) {
+    const int n8 = n & ~7;
+    return b < n8 ? (b & 7) * (n8 >> 3) + (b >> 3) : b;
+}
+// DEEPIPR_XCD_REMAP=0 switches the remap of the Winograd kernels off (A/B)
+DIPR_HIDDEN int dipr_xcd_remap();
+
 struct FwPlan {
     int cfg;        // 0: unsupported; >= 1000: a Winograd instance (1000 + width code * 100 + m blocks * 10 + k groups)
     int bands;      // row bands per image group

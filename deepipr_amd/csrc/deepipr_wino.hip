@@ -22,9 +22,10 @@ void launch(const FwPlan &p, const float *wgt, const float *in, float *out, int 
             hipEvent_t a, hipEvent_t b) {
     const dim3 grid(ws ? p.grid * p.splits : p.grid), block(C::NTH);
     const int cps = ws ? p.cps : Cin / C::CK;
+    const int xcd = dipr_xcd_remap();
     if (a) hipExtLaunchKernelGGL((k_conv_wino<C, DGRAD, PRE>), grid, block, 0, st, a, b, 0, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid,
-                                 cps, p.slab);
-    else hipLaunchKernelGGL((k_conv_wino<C, DGRAD, PRE>), grid, block, 0, st, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid, cps, p.slab);
+                                 cps, p.slab, xcd);
+    else hipLaunchKernelGGL((k_conv_wino<C, DGRAD, PRE>), grid, block, 0, st, wgt, in, out, N, Cin, M, H, p.bands, ws, p.grid, cps, p.slab, xcd);
 }
 
 template <bool DGRAD, bool PRE>
@@ -58,9 +59,9 @@ bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *p
 #define DIPR_WW(WW, TBR, NIB)                                                                                          \
     do {                                                                                                              \
         if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(256), 0, st, a, b, 0, x, dy, part, N, \
-                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split);                        \
+                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());      \
         else hipLaunchKernelGGL((k_conv_wino_wgrad<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(256), 0, st, x, dy, part, N, Ci, Co, H,   \
-                                tiles_co, tiles_ci, chunks, chunks_per_split);                                        \
+                                tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());                      \
         return true;                                                                                                  \
     } while (0)
     switch (width) {
@@ -75,9 +76,9 @@ bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *p
 #define DIPR_WX(...)                                                                                                  \
     do {                                                                                                              \
         if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad_x<WxCfg<__VA_ARGS__>>), dim3(grid), dim3(256), 0, st, a, b, 0, x, dy, part, N, \
-                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split);                        \
+                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());      \
         else hipLaunchKernelGGL((k_conv_wino_wgrad_x<WxCfg<__VA_ARGS__>>), dim3(grid), dim3(256), 0, st, x, dy, part, N, Ci, Co, H,   \
-                                tiles_co, tiles_ci, chunks, chunks_per_split);                                        \
+                                tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());                      \
         return true;                                                                                                  \
     } while (0)
     switch (width) {
@@ -88,6 +89,11 @@ bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *p
         default: return false;
     }
 #undef DIPR_WX
+}
+
+int dipr_xcd_remap() {
+    static const int v = (getenv("DEEPIPR_XCD_REMAP") && !atoi(getenv("DEEPIPR_XCD_REMAP"))) ? 0 : 1;
+    return v;
 }
 
 FwPlan dipr_plan_conv_wino(int N, int C, int M, int H, int W, int k, int stride, int pad) {
