@@ -2,6 +2,7 @@
 include/deepipr_hip.h (no compute calls here)."""
 import ctypes
 import os
+import sys
 import re
 
 from deepipr_amd import _lib
@@ -99,14 +100,22 @@ def test_kernels_do_not_spill_registers(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, 'deepipr_amd', 'csrc', 'deepipr_hip.hip')
     out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-                          '-ffp-contract=off', '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', '-c',
-                          '-o', str(tmp_path / 'k.o'), src], capture_output=True, text=True, cwd=str(tmp_path))
+                          '-ffp-contract=off', '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', '-S',
+                          '-o', str(tmp_path / 'k.s'), src], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
     names = re.findall(r'Function Name: (\S+)', out.stderr)
     scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out.stderr)]
     assert len(names) == len(scratch) and len(names) > 100
     spilled = {n: s for n, s in zip(names, scratch) if s}
     assert not spilled, spilled
+    # ... and the same listing must show no accumulator copies inside an MFMA loop (tools/isa_loop_moves.py: round 6 found 32
+    # v_mov_b64 per chunk pair in the 1x1 GEMM -- a loop with an exit in its middle -- worth 2 % of the ResNet50 step)
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from isa_loop_moves import innermost_mfma_loops
+    loops = innermost_mfma_loops(open(tmp_path / 'k.s').read())
+    assert len(loops) > 40, len(loops)
+    copies = [(mv, mf, fn) for mv, mf, fn in loops if mv > 2]
+    assert not copies, copies[:4]
 
 
 def test_integration_stub_matches_the_abi():

@@ -26,7 +26,8 @@ for k in sorted(d):
     print(k, {kk: d[k][kk] for kk in ('fetch', 'write', 'total', 'algorithmic', 'traffic_over_algorithmic', 'dispatches_fetch_pass') if kk in d[k]})
 PY
 }
-run r50 --arch resnet50 --image-size 224 --classes 1000 --batch 256 --no-miopen-find --steps 3 --warmup 1
-run R --steps 12 --warmup 4
+# PMC_CONFIGS: which steps to measure (default both; the ResNet50 passes take ~10 minutes each)
+case " ${PMC_CONFIGS:-r50 R} " in *" r50 "*) run r50 --arch resnet50 --image-size 224 --classes 1000 --batch 256 --no-miopen-find --steps 3 --warmup 1;; esac
+case " ${PMC_CONFIGS:-r50 R} " in *" R "*) run R --steps 12 --warmup 4;; esac
 # the raw per-dispatch CSVs are large: keep the summaries and the configuration-R CSVs only
 rm -f gpurun_out/r06_pmc_*_in_situ_r50.csv
