@@ -23,7 +23,9 @@ def run(n, c, hw, direction):
     x = torch.randn(n, c, hw, hw, device=dev)
     w = torch.randn(c, c, 3, 3, device=dev) * 0.05
     buf = torch.zeros(64 * 8192, dtype=torch.int64, device=dev)
-    fn = (lambda: K.conv_fwd(x, w, 1, 1)) if direction == 0 else (lambda: K.conv_dgrad(x, w, x.shape, 1, 1))
+    # the form the step runs: weights pre-transformed (k_wino_weights), DEEPIPR_TRACE_RAW=1 for the in-kernel transform
+    pre = None if os.environ.get('DEEPIPR_TRACE_RAW') == '1' else K.wino_transform([w])[0]
+    fn = (lambda: K.conv_fwd(x, w, 1, 1, pre)) if direction == 0 else (lambda: K.conv_dgrad(x, w, x.shape, 1, 1, pre))
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -44,10 +46,28 @@ def run(n, c, hw, direction):
         n, c, hw, 'fwd' if direction == 0 else 'dgr', us, len(t), wall[:, 0].max(), wall[:, 4].max())
     for i, nm in enumerate(names):
         line += ' %s %6.0f cyc (max %6.0f)' % (nm, cyc[:, i].mean(), cyc[:, i].max())
+    # effective shader clock while the kernel runs: shader cycles over wall time (100 MHz counter), entry -> stores issued, per workgroup
+    dcyc = (t[:, 4, 1] - t[:, 0, 1]).astype(np.float64)
+    dwall = (t[:, 4, 0] - t[:, 0, 0]).astype(np.float64) * 0.01
+    line += ' | shader clock %4.0f MHz (min %4.0f)' % ((dcyc / dwall).mean(), (dcyc / dwall).min())
     chunks = c // 8
     line += ' | %5.0f cyc/chunk' % (cyc[:, 1].mean() / max(1, chunks))
     line += ' | wall: loop starts %5.1f..%5.1f, ends %5.1f..%5.1f' % (wall[:, 1].min(), wall[:, 1].max(), wall[:, 2].min(), wall[:, 2].max())
     print(line, flush=True)
+    if os.environ.get('DEEPIPR_TRACE_PLACEMENT') == '1':
+        # which workgroups share a CU: (XCC, HW_ID bits 8-14) per workgroup index, the first 2 x CUs of them (the first round)
+        full = buf.view(-1, 32, 2).cpu().numpy().astype(np.int64)[:len(t)]
+        where = full[:, 31, 1] * 128 + full[:, 31, 0]
+        first = {}
+        for b in range(min(len(t), 512)):
+            first.setdefault(int(where[b]), []).append(b)
+        pairs = [v for v in first.values() if len(v) >= 2]
+        d = sorted({v[1] - v[0] for v in pairs})
+        print('      placement: %d distinct CUs among the first 512 workgroups, %d hold two or more; index distance of a CU\'s first two tenants: %s; examples %s'
+              % (len(first), len(pairs), d[:12], pairs[:4]), flush=True)
+        print('      XCC of workgroups 0..15:', full[:16, 31, 1].tolist(), ' HW_ID[14:8] of 0..15:', full[:16, 31, 0].tolist(), flush=True)
+    if not t[:, 5, 1].any():                                   # the pre-transformed form carries no per-step stamps
+        return
     steps = min(9, chunks)
     st = t[:, 5:5 + 3 * steps, 1].reshape(len(t), steps, 3)
     body, bar = (st[:, :, 1] - st[:, :, 0]), (st[:, :, 2] - st[:, :, 1])
