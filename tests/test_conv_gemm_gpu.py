@@ -124,6 +124,51 @@ def test_one_hot_operands_are_exact(K, k, st):
     assert torch.equal(y.double(), ry) and torch.equal(dx.double(), rdx)
 
 
+@pytest.mark.parametrize('n,h', [(5, 224), (2, 64), (1, 8)])
+def test_imagenet_stem_forward_matches_the_float64_oracle(K, n, h):
+    """k_conv_stem7_fwd (deepipr_conv_stem7.inc): Conv 3 -> 64, 7x7, stride 2, pad 3 on 224-wide images
+    (models/resnet_passport.py:94-98), any height that is a multiple of 8.  1e-5 of scale against float64 (147 products per
+    output), bit-reproducible; the band borders (first / last rows of an image, the halo rows between bands) are where a wrong
+    row offset shows, so the error is also taken per output row."""
+    assert K.conv_supported(n, 3, 64, h, 224, 7, 2, 3, 0) and not K.conv_supported(n, 3, 64, h, 224, 7, 2, 3, 1)
+    x, wt = _rand((n, 3, h, 224), 31 + n), _rand((64, 3, 7, 7), 32 + h, 0.1)
+    y = K.conv_fwd(x, wt, 2, 3)
+    assert y is not None and y.shape == (n, 64, h // 2, 112)
+    ref = _conv64(x, wt, 2, 3)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * scale
+    per_row = (y.double() - ref).abs().amax(dim=(0, 1, 3))
+    assert float(per_row.max()) <= 1e-5 * scale, per_row
+    assert torch.equal(y, K.conv_fwd(x, wt, 2, 3))
+
+
+def test_imagenet_stem_forward_is_exact_on_small_integers(K):
+    """Every tap, every border: small-integer images and filters (all 147 taps non-zero, values in -3 .. 3) give sums below 2^24 --
+    the fp32 result must EQUAL the float64 one, in particular in the first / last three rows and columns (the zero padding) and
+    in the padded eighth column of the kernel's K layout (a non-zero there would show as an exact mismatch)."""
+    rs = np.random.RandomState(7)
+    n, h = 3, 32
+    x = torch.from_numpy(rs.randint(-3, 4, size=(n, 3, h, 224)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy(rs.randint(-3, 4, size=(64, 3, 7, 7)).astype(np.float32)).to(DEV)
+    y, ref = K.conv_fwd(x, w, 2, 3), _conv64(x, w, 2, 3)
+    assert float(ref.abs().max()) > 50
+    assert torch.equal(y.double(), ref)
+    # one-hot filters: output = one shifted, subsampled image plane
+    w1 = torch.zeros(64, 3, 7, 7, device=DEV)
+    for m in range(64):
+        w1[m, m % 3, (m * 5) % 7, (m * 3) % 7] = 1.0
+    assert torch.equal(K.conv_fwd(x, w1, 2, 3).double(), _conv64(x, w1, 2, 3))
+
+
+@pytest.mark.parametrize('case', [dict(ci=3, co=64, k=7, st=2, pad=3, h=56, wd=112), dict(ci=3, co=32, k=7, st=2, pad=3, h=224, wd=224),
+                                  dict(ci=3, co=64, k=7, st=2, pad=3, h=12, wd=224), dict(ci=3, co=64, k=7, st=2, pad=2, h=224, wd=224),
+                                  dict(ci=4, co=64, k=7, st=2, pad=3, h=224, wd=224)])
+def test_stem_shapes_outside_the_kernel_are_refused(K, case):
+    assert not K.conv_supported(2, case['ci'], case['co'], case['h'], case['wd'], case['k'], case['st'], case['pad'], 0)
+    x, w = _rand((2, case['ci'], case['h'], case['wd']), 1), _rand((case['co'], case['ci'], case['k'], case['k']), 2)
+    assert K.conv_fwd(x, w, case['st'], case['pad']) is None
+
+
 @pytest.mark.parametrize('case', [dict(ci=3, co=64), dict(ci=64, co=96), dict(h=14), dict(k=5, pad=2), dict(k=1, pad=0, st=1, ci=32), dict(k=1, pad=1, st=1),
                                   dict(h=64, st=2), dict(n=3, h=4), dict(k=3, pad=0)])
 def test_shapes_outside_the_kernels_are_refused(K, case):

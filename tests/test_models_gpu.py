@@ -329,6 +329,12 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
     from deepipr_amd.models.layers.conv2d import ConvBlock
     monkeypatch.setenv('DEEPIPR_TAIL_FUSION', '0')
     tol = 1e-4
+    # the band around a ReLU kink inside which an element is taken out of BOTH nets: it has to cover the forward error the fp32
+    # net has accumulated at that depth, or an element just outside it can still be masked differently.  1e-4 covers every
+    # configuration of the 18-layer nets and AlexNet; fifty layers deep (config 5) single elements of the 532 M activations come
+    # within 1e-4 of their float64 value -- which stem kernel ran decided whether one of them flipped -- so the band is wider
+    # there (more elements gated, 0.1 % of them; the bar on values and gradients stays 1e-4)
+    band = tol * float(os.environ.get('DEEPIPR_TEST_KINK_BAND', 2.0 if case == 'resnet50_imagenet' else 1.0))
     arch, private, n, ncls, norm = WHOLE_NET_CASES[case][:5]
     prod, ref, x, y = _whole_net_pair(arch, private, n, ncls, norm, *WHOLE_NET_CASES[case][5:])
     ref = ref.double().to(DEV)
@@ -400,7 +406,7 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
             hooks.append(m.register_forward_hook(tie_hook(found_ties, name)))
             if ties:
                 hooks.append(m.register_forward_hook(gate(ties[name], torch.float64)))
-        torch_ref.F = _RecordingF(state, tol)
+        torch_ref.F = _RecordingF(state, band)
         try:
             with torch.no_grad():
                 ref_forward()
@@ -419,7 +425,7 @@ def test_whole_net_backward_within_1e4_with_relu_kinks_gated(case, monkeypatch):
         rounds += 1
         if rounds > 1 and added == 0:
             break
-        assert rounds < 8, 'the near-kink search does not settle'
+        assert rounds < 12, 'the near-kink search does not settle'
     assert ({k for k in near if not k.startswith('tail:')} == {k for k, _ in ref_layers}
             and {k[5:] for k in near if k.startswith('tail:')} == {k for k, _ in ref_blocks}
             and all(len(v) == len(inds) for v in near.values()))

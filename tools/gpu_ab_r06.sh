@@ -13,8 +13,10 @@ for r in $(seq 1 ${AB_ROUNDS:-2}); do
   for v in head new; do
     unset DEEPIPR_LIB
     [ $v = head ] && export DEEPIPR_LIB=$HEADLIB
-    timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-stress --no-configs 2>/dev/null | tail -1 > $O/bench_R_${v}_$r.json
-    python -c "import json; d=json.load(open('$O/bench_R_${v}_$r.json')); k=d.get('roofline_mfma_kernels',{}); print('$v $r R', d['ms_per_step'], d['value'], {n:r.get('avg_us') for n,r in k.items() if 'wino' in n} if isinstance(k,dict) else '')"
+    if [ -z "$AB_NO_R" ]; then
+      timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-stress --no-configs 2>/dev/null | tail -1 > $O/bench_R_${v}_$r.json
+      python -c "import json; d=json.load(open('$O/bench_R_${v}_$r.json')); k=d.get('roofline_mfma_kernels',{}); print('$v $r R', d['ms_per_step'], d['value'], {n:r.get('avg_us') for n,r in k.items() if 'wino' in n} if isinstance(k,dict) else '')"
+    fi
     if [ -z "$AB_NO_R50" ]; then
       timeout 400 python bench.py --arch resnet50 --image-size 224 --classes 1000 --batch 256 --no-miopen-find --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-configs 2>/dev/null | tail -1 > $O/bench_r50_${v}_$r.json
       python -c "import json; d=json.load(open('$O/bench_r50_${v}_$r.json')); print('$v $r R50', d['ms_per_step'], d['value'])"
