@@ -4600,6 +4600,17 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
                        p.splits);
         return check_launch("conv_wgrad");
     }
+    if (p.cfg == 3700) {                                                 // the ImageNet stem (deepipr_conv_stem7.inc)
+        if (rank2) return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no fused rank-2 term for a 3-channel input");
+        {
+            ProfScope prof(DEEPIPR_K_CONV_WGRAD, st);
+            prof.bytes = 2.0 * Co * 147.0 * static_cast<double>(N) * (H / 2) * (W / 2);
+            DEEPIPR_LAUNCH(prof, k_conv_stem7_wgrad, dim3(p.splits), dim3(512), st, x, dy, part, N, H, p.chunks_per_split);
+        }
+        ProfScope prof(DEEPIPR_K_CONV_WGRAD_REDUCE, st);
+        DEEPIPR_LAUNCH(prof, k_conv_stem7_wgrad_reduce, dim3(64), dim3(256), st, part, dW, p.splits);
+        return check_launch("conv_wgrad");
+    }
     if (p.cfg >= 6000) {                                               // 1x1 stride 1 (deepipr_conv_1x1.inc)
         ProfScope prof(DEEPIPR_K_CONV1X1_WGRAD, st);
         prof.bytes = 2.0 * Co * Ci * static_cast<double>(N) * H * W;    // FLOPs

@@ -474,6 +474,8 @@ int deepipr_upsample2_zero(const float *dy, float *dx, size_t planes, int H, int
  *                        (the projection shortcuts; models/resnet_passport.py:33-36);
  *   3x3 pad 1 stride 1 with Ci = 3 on 32-wide maps, H a multiple of 4 (the CIFAR stem): NO fused rank-2 term -- with dgamma /
  *                        dbeta / m the call returns DEEPIPR_EUNSUPPORTED (add it with deepipr_gamma_beta_bwd_acc).
+ *   7x7 pad 3 stride 2 with Ci = 3, Co = 64 on 224-wide images, H even (the ImageNet stem, models/resnet_passport.py:94-98;
+ *                        deepipr_conv_stem7.inc): no fused rank-2 term either; replaces igemm_wrw_gtcx35_nhwc + its transposes.
  * Anything else: deepipr_conv_wgrad_workspace_bytes returns 0 and deepipr_conv_wgrad returns DEEPIPR_EUNSUPPORTED without
  * enqueuing anything -- the caller keeps the library's wgrad.
  * replaces: the weight half of aten::convolution_backward behind `self.conv(x)`,
@@ -513,7 +515,7 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
  *   whole row bands: the output height a multiple of 8 / 8 / 4 / 2 (32-, 16-, 8-, 4-wide maps), N a multiple of 4 on 4-wide maps;
  *   1x1 pad 0 stride 1 on any map (both directions; ABI v11): one GEMM over the flattened (image, pixel) positions, the
  *   Bottleneck's convolutions (models/resnet_normal.py:30-49); N * H * W * max(Ci, Co) below 2^31.
- *   7x7 pad 3 stride 2, Ci = 3, Co = 64, W = 224, H a multiple of 8 (forward only): the ImageNet stem (models/resnet_passport.py:
+ *   7x7 pad 3 stride 2, Ci = 3, Co = 64, W = 224, H a multiple of 8 (forward only -- the image has no gradient): the ImageNet stem (models/resnet_passport.py:
  *   94-98; replaces miopenSp3AsmConv_*_f3x2_stride2 + its CNHW transposes), deepipr_conv_stem7.inc.
  * Anything else returns DEEPIPR_EUNSUPPORTED without enqueuing anything: the caller keeps the library's convolution.
  * replaces: aten::convolution / the data half of aten::convolution_backward behind `self.conv(x)`,

@@ -86,6 +86,40 @@ def test_wgrad_matches_the_float64_oracle_and_is_bit_reproducible(K, shape):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize('n,h', [(5, 224), (3, 64), (1, 8), (2, 226)])
+def test_imagenet_stem_wgrad_matches_the_float64_oracle(n, h):
+    """k_conv_stem7_wgrad (deepipr_conv_stem7.inc): the weight gradient of Conv 3 -> 64, 7x7, stride 2, pad 3 on 224-wide images
+    (models/resnet_passport.py:94-98).  K = N * H / 2 * 112 output positions summed in fp32 (up to 62 720 here; 3.2 M at batch
+    256): 1e-5 of scale against float64, bit-reproducible (fixed order: wavefronts in LDS, workgroups in the reduce launch)."""
+    from deepipr_amd.passport_ops import kernels as K
+    assert K.conv_wgrad_workspace(n, 3, 64, h, 224, 7, 7, 2, 3) > 0
+    x, dy = _rand((n, 3, h, 224), 41 + n), _rand((n, 64, h // 2, 112), 42 + h)
+    got = K.conv_wgrad(x, dy, (64, 3, 7, 7), 2, 3)
+    assert got is not None and got.shape == (64, 3, 7, 7) and got.is_contiguous()
+    ref = _ref(x, dy, (64, 3, 7, 7), 2, 3)
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(got, K.conv_wgrad(x, dy, (64, 3, 7, 7), 2, 3))
+
+
+def test_imagenet_stem_wgrad_is_exact_on_small_integers_and_sees_the_padding():
+    """Small-integer x and dy (sums below 2^24): the fp32 result EQUALS the float64 one -- every tap, the three zero rows /
+    columns around the image, the idle lanes behind tap 146; then one-hot operands at the image corners."""
+    from deepipr_amd.passport_ops import kernels as K
+    rs = np.random.RandomState(11)
+    n, h = 3, 32
+    x = torch.from_numpy(rs.randint(-3, 4, size=(n, 3, h, 224)).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rs.randint(-2, 3, size=(n, 64, h // 2, 112)).astype(np.float32)).to(DEV)
+    got, ref = K.conv_wgrad(x, dy, (64, 3, 7, 7), 2, 3), _ref(x, dy, (64, 3, 7, 7), 2, 3)
+    assert float(ref.abs().max()) > 100
+    assert torch.equal(got.double(), ref)
+    x1, dy1 = torch.zeros_like(x), torch.zeros_like(dy)
+    for (a, b) in [(0, 0), (0, 223), (h - 1, 0), (h - 1, 223), (5, 100)]:
+        x1[rs.randint(n), rs.randint(3), a, b] = float(rs.randint(1, 5))
+    for (a, b) in [(0, 0), (0, 111), (h // 2 - 1, 0), (h // 2 - 1, 111), (2, 50)]:
+        dy1[:, rs.randint(64), a, b] = float(rs.randint(1, 5))
+    assert torch.equal(K.conv_wgrad(x1, dy1, (64, 3, 7, 7), 2, 3).double(), _ref(x1, dy1, (64, 3, 7, 7), 2, 3))
+
+
 @pytest.mark.parametrize('st', [1, 2])
 def test_wgrad_sees_the_zero_padding_and_every_tap(K, st):
     """One-hot dy / x: every dW entry is a single product, so a wrong tap offset, a halo column that is not zero or a

@@ -40,6 +40,17 @@ def main():
     flops = 2.0 * 64 * 147 * a.batch * 112 * 112
     us = timeit(lambda: K.conv_fwd(x, w, 2, 3), a.reps)
     us_lib = timeit(lambda: torch.nn.functional.conv2d(x, w, None, 2, 3), a.reps)
+    dy = torch.randn_like(y)
+    dw = K.conv_wgrad(x, dy, (64, 3, 7, 7), 2, 3)
+
+    def lib_wgrad():
+        return torch.ops.aten.convolution_backward(dy, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    dw_lib = lib_wgrad()
+    wus = timeit(lambda: K.conv_wgrad(x, dy, (64, 3, 7, 7), 2, 3), a.reps)
+    wus_lib = timeit(lib_wgrad, a.reps)
+    print(json.dumps({'batch': a.batch, 'wgrad_us': round(wus, 1), 'wgrad_useful_TFLOPs': round(flops / wus / 1e6, 1),
+                      'wgrad_GBs': round(4.0 * (x.numel() + dy.numel()) / wus / 1e3, 1), 'wgrad_library_us': round(wus_lib, 1),
+                      'wgrad_max_diff_vs_library_of_scale': float((dw - dw_lib).abs().max() / dw_lib.abs().max())}))
     print(json.dumps({'batch': a.batch, 'fwd_us': round(us, 1), 'useful_TFLOPs': round(flops / us / 1e6, 1),
                       'executed_TFLOPs': round(flops * (168 / 147) * (32 / 28) / us / 1e6, 1),
                       'GBs': round(4.0 * (x.numel() + y.numel()) / us / 1e3, 1), 'library_us': round(us_lib, 1),
