@@ -4750,12 +4750,13 @@ int conv_gemm(int slot, const float *wgt, const float *in, float *out, int N, in
     const FwPlan p = plan_conv_any(N, Cin, M, H, W, k, stride, pad);
     if (p.cfg >= 1000) return conv_wino<DGRAD>(p, wgt, in, out, N, Cin, M, H, W, st, what, workspace, workspace_bytes);
     if (!p.cfg) return fail(DEEPIPR_EUNSUPPORTED, "%s: shape outside the kernel (use the library's convolution)", what);
-    if (p.cfg == 700) {                                                  // the 7x7 stride-2 ImageNet stem (deepipr_conv_stem7.inc)
+    if (p.cfg == 700 || p.cfg == 600) {                                  // the stems: 7x7 stride 2 (ImageNet), 3x3 stride 1 (CIFAR); deepipr_conv_stem7.inc
         if (DGRAD) return fail(DEEPIPR_EUNSUPPORTED, "%s: the stem has no backward-data instance (its input is the image)", what);
         if (!aligned16(wgt) || !aligned16(in) || !aligned16(out)) return fail(DEEPIPR_EINVAL, "%s: pointers must be 16-byte aligned", what);
         ProfScope prof(slot, st);
-        prof.bytes = 2.0 * M * Cin * 49.0 * static_cast<double>(N) * (H / 2) * (W / 2);        // useful FLOPs (executed: x 168 / 147 x 32 / 28)
-        DEEPIPR_LAUNCH(prof, k_conv_stem7_fwd, dim3(p.grid), dim3(256), st, wgt, in, out, N, H);
+        prof.bytes = 2.0 * M * Cin * k * k * static_cast<double>(N) * (H / stride) * (W / stride);     // useful FLOPs (the padded taps / idle lanes not counted)
+        if (p.cfg == 700) DEEPIPR_LAUNCH(prof, k_conv_stem7_fwd, dim3(p.grid), dim3(256), st, wgt, in, out, N, H);
+        else DEEPIPR_LAUNCH(prof, k_conv_stem3_fwd, dim3(p.grid), dim3(256), st, wgt, in, out, N, H);
         return check_launch(what);
     }
     if (p.cfg >= 900) {                                                  // 1x1 stride 1: one GEMM over NCHW (deepipr_conv_1x1.inc)

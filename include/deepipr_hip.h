@@ -515,6 +515,7 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
  *   whole row bands: the output height a multiple of 8 / 8 / 4 / 2 (32-, 16-, 8-, 4-wide maps), N a multiple of 4 on 4-wide maps;
  *   1x1 pad 0 stride 1 on any map (both directions; ABI v11): one GEMM over the flattened (image, pixel) positions, the
  *   Bottleneck's convolutions (models/resnet_normal.py:30-49); N * H * W * max(Ci, Co) below 2^31.
+ *   3x3 pad 1 stride 1, Ci = 3, Co = 64, W = 32, H a multiple of 8 (forward only): the CIFAR stem (models/resnet_passport.py:99-101);
  *   7x7 pad 3 stride 2, Ci = 3, Co = 64, W = 224, H a multiple of 8 (forward only -- the image has no gradient): the ImageNet stem (models/resnet_passport.py:
  *   94-98; replaces miopenSp3AsmConv_*_f3x2_stride2 + its CNHW transposes), deepipr_conv_stem7.inc.
  * Anything else returns DEEPIPR_EUNSUPPORTED without enqueuing anything: the caller keeps the library's convolution.

@@ -160,6 +160,24 @@ def test_imagenet_stem_forward_is_exact_on_small_integers(K):
     assert torch.equal(K.conv_fwd(x, w1, 2, 3).double(), _conv64(x, w1, 2, 3))
 
 
+@pytest.mark.parametrize('n,h', [(128, 32), (5, 32), (2, 8), (3, 64)])
+def test_cifar_stem_forward_matches_the_float64_oracle_and_is_exact_on_small_integers(K, n, h):
+    """k_conv_stem3_fwd: Conv 3 -> 64, 3x3, stride 1, pad 1 on 32-wide images (models/resnet_passport.py:99-101) -- the last
+    convolution of the headline configuration that ran in the vendor library.  1e-5 of scale against float64, bit-reproducible;
+    small integers exact (every tap, the zero padding, the padded fourth kernel column)."""
+    assert K.conv_supported(n, 3, 64, h, 32, 3, 1, 1, 0) and not K.conv_supported(n, 3, 64, h, 32, 3, 1, 1, 1)
+    x, wt = _rand((n, 3, h, 32), 51 + n), _rand((64, 3, 3, 3), 52 + h, 0.2)
+    y = K.conv_fwd(x, wt, 1, 1)
+    assert y is not None and y.shape == (n, 64, h, 32)
+    ref = _conv64(x, wt, 1, 1)
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(y, K.conv_fwd(x, wt, 1, 1))
+    rs = np.random.RandomState(n + h)
+    xi = torch.from_numpy(rs.randint(-4, 5, size=(n, 3, h, 32)).astype(np.float32)).to(DEV)
+    wi = torch.from_numpy(rs.randint(-4, 5, size=(64, 3, 3, 3)).astype(np.float32)).to(DEV)
+    assert torch.equal(K.conv_fwd(xi, wi, 1, 1).double(), _conv64(xi, wi, 1, 1))
+
+
 @pytest.mark.parametrize('case', [dict(ci=3, co=64, k=7, st=2, pad=3, h=56, wd=112), dict(ci=3, co=32, k=7, st=2, pad=3, h=224, wd=224),
                                   dict(ci=3, co=64, k=7, st=2, pad=3, h=12, wd=224), dict(ci=3, co=64, k=7, st=2, pad=2, h=224, wd=224),
                                   dict(ci=4, co=64, k=7, st=2, pad=3, h=224, wd=224)])
