@@ -56,6 +56,9 @@ SIGNATURES = {
     'deepipr_ce_top1_workspace_bytes': (_sz, [_int]),
     'deepipr_ce_top1_fwd': (_int, [_f32p, _vp, _int, _int, _f32p, _f32p, _f32p, _vp, _vp]),
     'deepipr_ce_bwd': (_int, [_f32p, _f32p, _vp, _f32p, _int, _int, _f32p, _vp]),
+    'deepipr_pooled_linear_supported': (_int, [_int, _int, _int, _int]),
+    'deepipr_pooled_linear_fwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _vp]),
+    'deepipr_pooled_linear_bwd': (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _vp]),
     'deepipr_scalar_sums': (_int, [_vp, _int, _int, _f32p, _vp]),
     'deepipr_add_relu_fwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
     'deepipr_relu_bwd': (_int, [_f32p, _f32p, _f32p, _sz, _vp]),
@@ -121,7 +124,7 @@ TEST_HOOK_SIGNATURES = {
     'deepipr_debug_trace': (_int, [_vp]),
     'deepipr_debug_wino_trace': (_int, [_vp]),
 }
-ABI_VERSION = 11
+ABI_VERSION = 12
 SYNC_WORDS = 2 * (256 * 30 * 4 + 4096 + 63 * 2048) + 16     # DEEPIPR_SYNC_WORDS
 SYNC_TIMEOUT_WORD = 2 * (256 * 30 * 4 + 4096 + 63 * 2048)   # DEEPIPR_SYNC_TIMEOUT_WORD
 
@@ -193,7 +196,7 @@ PROFILE_KERNELS = ['pooled_patch_mean', 'gamma_beta_fwd', 'gamma_beta_bwd', 'aff
                    'reduce_partials', 'passport_bwd_finish', 'sign_loss_fwd', 'sign_loss_bwd', 'dkey', 'reserved',
                    'bn_stats', 'bn_affine_fwd', 'bn_bwd_reduce', 'bn_affine_bwd', 'sgd', 'add_relu', 'bn_res_fwd',
                    'bn_res_bwd', 'gn_fwd', 'gn_bwd', 'conv_wgrad', 'conv_wgrad_reduce', 'conv_fwd', 'conv_dgrad', 'conv_wgrad_b3', 'conv_split_sum',
-                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad', 'maxpool', 'resample2', 'conv1x1_fwd', 'conv1x1_dgrad']
+                   'conv_wino_fwd', 'conv_wino_dgrad', 'conv_wino_wgrad', 'conv_wino_weights', 'conv1x1_wgrad', 'maxpool', 'resample2', 'conv1x1_fwd', 'conv1x1_dgrad', 'head']
 
 
 class ExternalEvent:

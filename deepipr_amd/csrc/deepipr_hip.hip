@@ -2773,6 +2773,107 @@ __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float *__restrict__ d
 
 
 // ============================================================================================
+// The classifier of the CIFAR-geometry nets: logits = Linear(avg_pool(x))  (models/resnet_passport.py:226-228 of this package =
+// the reference's `out = F.avg_pool2d(out, 4); out = out.view(out.size(0), -1); out = self.linear(out)`, models/resnet_passport.py:
+// 127-129 there) in ONE launch, its backward in one.  The library path is five launch-latency-bound kernels forward and backward
+// (mean reduce 8 us, a 128 x 512 x 10 GEMM the BLAS library takes 16 us for, two more GEMMs, a broadcast-divide, a bias reduce:
+// 65 us of the 3.5 ms step); the data is 4 MB.
+//   forward  workgroup = (image, eight classes): the channel means (kept for the backward) through LDS, then a wavefront per class:
+//            lanes stride over the channels, butterfly sum (fixed order), + bias.
+//   backward the first N x C / 256 workgroups: dx[n][c][:] = (sum_k dlogits[n][k] W[k][c]) / HW, a thread per channel;
+//            the others: dW for 64 channels x 8 classes (+ db from the channel block 0 ones): four image groups, each a
+//            sequential sum over its images, combined in group order through LDS -- bit-reproducible.
+// ============================================================================================
+constexpr int kHeadMaxC = 4096, kHeadMaxK = 128;
+
+__global__ __launch_bounds__(kThreads) void k_pooled_linear_fwd(const float *__restrict__ x, const float *__restrict__ W,
+                                                                const float *__restrict__ b, float *__restrict__ pooled,
+                                                                float *__restrict__ logits, int C, int HW, int K, int kblocks) {
+    // workgroup = (image n, block of eight classes): every class block pools the image again (32 KB from L2) rather than wait
+    // for one that did -- 100 classes are 13 x N workgroups instead of N
+    __shared__ float mean_s[kHeadMaxC];
+    const int n = blockIdx.x / kblocks, kb = blockIdx.x - n * kblocks;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float inv = 1.0f / static_cast<float>(HW);
+    const float *xn = x + static_cast<size_t>(n) * C * HW;
+    for (int c = t; c < C; c += kThreads) {
+        const float4 *row = reinterpret_cast<const float4 *>(xn + static_cast<size_t>(c) * HW);
+        float s = 0.0f;
+        for (int q = 0; q < HW / 4; ++q) {
+            const float4 v = row[q];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        s *= inv;
+        mean_s[c] = s;
+        if (kb == 0) pooled[static_cast<size_t>(n) * C + c] = s;
+    }
+    __syncthreads();
+    for (int k = kb * 8 + wave; k < min(K, kb * 8 + 8); k += kThreads / kWave) {
+        const float *wk = W + static_cast<size_t>(k) * C;
+        float s = 0.0f;
+        for (int c = lane; c < C; c += kWave) s = fmaf(mean_s[c], wk[c], s);
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+        if (lane == 0) logits[static_cast<size_t>(n) * K + k] = s + (b ? b[k] : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_pooled_linear_bwd(const float *__restrict__ dl, const float *__restrict__ W,
+                                                                const float *__restrict__ pooled, float *__restrict__ dx,
+                                                                float *__restrict__ dW, float *__restrict__ db, int N, int C,
+                                                                int HW, int K) {
+    __shared__ float sh[kThreads * 8 + kHeadMaxK];
+    const int t = threadIdx.x;
+    const int slabs = (C + kThreads - 1) / kThreads;               // dx workgroups per image: 256 channels each
+    if (static_cast<int>(blockIdx.x) < N * slabs) {
+        const int n = blockIdx.x / slabs, c = (blockIdx.x - n * slabs) * kThreads + t;
+        float *dls = sh;
+        for (int k = t; k < K; k += kThreads) dls[k] = dl[static_cast<size_t>(n) * K + k];
+        __syncthreads();
+        if (c >= C) return;
+        float g = 0.0f;
+        for (int k = 0; k < K; ++k) g = fmaf(dls[k], W[static_cast<size_t>(k) * C + c], g);       // coalesced over the channels
+        g *= 1.0f / static_cast<float>(HW);
+        float4 *o = reinterpret_cast<float4 *>(dx + (static_cast<size_t>(n) * C + c) * HW);
+        for (int q = 0; q < HW / 4; ++q) o[q] = make_float4(g, g, g, g);
+        return;
+    }
+    // dW[k0 .. k0 + 7][c0 .. c0 + 63]: thread = (channel lane, image group g of four); group g sums images g, g + 4, ... in order
+    const int cblocks = C / 64, j = blockIdx.x - N * slabs, cb = j % cblocks, kb = j / cblocks;
+    const int c = cb * 64 + (t & 63), g = t >> 6, k0 = kb * 8;
+    float acc[8], accb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = accb[e] = 0.0f;
+    for (int n = g; n < N; n += 4) {
+        const float pv = pooled[static_cast<size_t>(n) * C + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = k0 + e < K ? dl[static_cast<size_t>(n) * K + k0 + e] : 0.0f;
+            acc[e] = fmaf(d, pv, acc[e]);
+            accb[e] += d;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[t * 8 + e] = acc[e];
+    float *bsh = sh + kThreads * 8;
+    if ((t & 63) == 0 && cb == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsh[g * 8 + e] = accb[e];
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (k0 + e < K) {
+                const float v = ((sh[t * 8 + e] + sh[(t + 64) * 8 + e]) + sh[(t + 128) * 8 + e]) + sh[(t + 192) * 8 + e];
+                dW[static_cast<size_t>(k0 + e) * C + c] = v;
+            }
+        }
+        if (cb == 0 && db && t < 8 && k0 + t < K) db[k0 + t] = ((bsh[t] + bsh[8 + t]) + bsh[16 + t]) + bsh[24 + t];
+    }
+}
+
+// ============================================================================================
 // Residual tail of a block: out = relu(a + b)  (models/resnet_passport.py:77-84: out += shortcut; F.relu(out)).
 // One 12 B/elt pass instead of ATen's add (12 B/elt) + relu (8 B/elt); backward is one masked copy shared by
 // both inputs: d = dy * [out > 0].
@@ -4212,6 +4313,39 @@ int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int
                        lse, part);
     hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(kThreads), 0, st, part, N, loss, top1_pct);
     return check_launch("ce_top1_fwd");
+}
+
+int deepipr_pooled_linear_supported(int N, int C, int HW, int K) {
+    return (N > 0 && C > 0 && C % 64 == 0 && C <= kHeadMaxC && HW > 0 && HW % 4 == 0 && HW <= 256 && K > 0 && K <= kHeadMaxK
+            && static_cast<long long>(N) * C * HW < (1ll << 31)) ? 1 : 0;
+}
+
+int deepipr_pooled_linear_fwd(const float *x, const float *W, const float *b, float *pooled, float *logits, int N, int C, int HW,
+                              int K, void *stream) {
+    if (!x || !W || !pooled || !logits) return fail(DEEPIPR_EINVAL, "pooled_linear_fwd: null pointer");
+    if (!deepipr_pooled_linear_supported(N, C, HW, K))
+        return fail(DEEPIPR_EUNSUPPORTED, "pooled_linear_fwd: C a multiple of 64 up to %d, HW a multiple of 4, at most %d classes "
+                    "(use the library's pooling + Linear)", kHeadMaxC, kHeadMaxK);
+    if (!aligned16(x)) return fail(DEEPIPR_EINVAL, "pooled_linear_fwd: x must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_HEAD, st);
+    prof.bytes = 4.0 * (static_cast<double>(N) * C * HW + static_cast<double>(N) * C + static_cast<double>(K) * C);
+    const int kblocks = (K + 7) / 8;
+    DEEPIPR_LAUNCH(prof, k_pooled_linear_fwd, dim3(N * kblocks), dim3(kThreads), st, x, W, b, pooled, logits, C, HW, K, kblocks);
+    return check_launch("pooled_linear_fwd");
+}
+
+int deepipr_pooled_linear_bwd(const float *dlogits, const float *W, const float *pooled, float *dx, float *dW, float *db, int N,
+                              int C, int HW, int K, void *stream) {
+    if (!dlogits || !W || !pooled || !dx || !dW) return fail(DEEPIPR_EINVAL, "pooled_linear_bwd: null pointer");
+    if (!deepipr_pooled_linear_supported(N, C, HW, K)) return fail(DEEPIPR_EUNSUPPORTED, "pooled_linear_bwd: shape outside the kernel");
+    if (!aligned16(dx)) return fail(DEEPIPR_EINVAL, "pooled_linear_bwd: dx must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_HEAD, st);
+    prof.bytes = 4.0 * (static_cast<double>(N) * C * HW + static_cast<double>(N) * C + 2.0 * K * C);
+    const int grid = N * ((C + kThreads - 1) / kThreads) + (C / 64) * ((K + 7) / 8);
+    DEEPIPR_LAUNCH(prof, k_pooled_linear_bwd, dim3(grid), dim3(kThreads), st, dlogits, W, pooled, dx, dW, db, N, C, HW, K);
+    return check_launch("pooled_linear_bwd");
 }
 
 int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,

@@ -18,7 +18,7 @@ from deepipr_amd.models._builders import ind_matters, shared_trunk, trunk_sharin
 from deepipr_amd.models.layers.conv2d import dual_tail
 from deepipr_amd.models.layers.passportconv2d import PassportBlock
 from deepipr_amd.models.layers.passportconv2d_private import PassportPrivateBlock
-from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, max_pool, stage_groups, with_wino_weights
+from deepipr_amd.passport_ops import conv2d, gamma_beta_batch, max_pool, pooled_linear, stage_groups, with_wino_weights
 
 
 _SHARED_CONV = os.environ.get('DEEPIPR_NO_SHARED_CONV') != '1'      # read once, at import (A/B switch)
@@ -224,8 +224,8 @@ class ResNetPassport(nn.Module):
         return all(hasattr(block, 'lockstep_ok') and block.lockstep_ok(x) for _li, _bi, block in post)
 
     def _head(self, out):
-        out = F.adaptive_avg_pool2d(out, (1, 1))
-        return self.linear(out.view(out.size(0), -1))
+        # avg-pool to 1x1 + Linear: one launch per direction on the CIFAR-geometry heads (passport_ops.pooled_linear)
+        return pooled_linear(self.linear, out)
 
     @with_wino_weights
     def forward(self, x, force_passport=False, ind=0):

@@ -697,6 +697,35 @@ class HipKernels:
                                                 lse.data_ptr(), n, c, dlogits.data_ptr(), _stream(dev)), 'ce_bwd')
         return dlogits
 
+    # ---- the CIFAR-geometry classifier: avg-pool + Linear in one launch (include/deepipr_hip.h: deepipr_pooled_linear_*) ----
+    def pooled_linear_supported(self, n, c, hw, k):
+        return bool(_lib.lib().deepipr_pooled_linear_supported(n, c, hw, k))
+
+    def pooled_linear_fwd(self, x, weight, bias):
+        """-> logits [N, K] = Linear(mean over the map of x [N, C, H, W]), pooled [N, C] (for the backward)."""
+        dev = _chk(x, weight, bias)
+        n, c, h, w = x.shape
+        k = weight.shape[0]
+        pooled = torch.empty((n, c), dtype=torch.float32, device=dev)
+        logits = torch.empty((n, k), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_pooled_linear_fwd(x.data_ptr(), weight.data_ptr(), _p(bias), pooled.data_ptr(),
+                                                           logits.data_ptr(), n, c, h * w, k, _stream(dev)), 'pooled_linear_fwd')
+        return logits, pooled
+
+    def pooled_linear_bwd(self, dlogits, weight, pooled, x_shape, with_bias):
+        """-> dx [N, C, H, W], dW [K, C], db [K] (None without a bias)."""
+        dev = _chk(dlogits, weight, pooled)
+        n, c, h, w = x_shape
+        k = weight.shape[0]
+        dx = torch.empty(x_shape, dtype=torch.float32, device=dev)
+        dw = torch.empty_like(weight)
+        db = torch.empty(k, dtype=torch.float32, device=dev) if with_bias else None
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_pooled_linear_bwd(dlogits.data_ptr(), weight.data_ptr(), pooled.data_ptr(), dx.data_ptr(),
+                                                           dw.data_ptr(), _p(db), n, c, h * w, k, _stream(dev)), 'pooled_linear_bwd')
+        return dx, dw, db
+
     # ---- data convolution: weight gradient on the fp32 matrix cores (include/deepipr_hip.h: deepipr_conv_wgrad) ----
     _wgrad_ws = {}
 
@@ -2074,6 +2103,46 @@ def scalar_sums(a_terms, b_terms):
         return total
     a, b = chain(a_terms), chain(b_terms)
     return a, b, (a if b is None else (b if a is None else a + b))
+
+
+class _PooledLinear(torch.autograd.Function):
+    """logits = Linear(avg_pool_to_1x1(x).flatten(1)) in one launch, backward in one (deepipr_pooled_linear_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = x.contiguous(), weight.contiguous()
+        logits, pooled = kernels.pooled_linear_fwd(x, weight, None if bias is None else bias.contiguous())
+        ctx.save_for_backward(weight, pooled)
+        ctx.x_shape, ctx.with_bias = tuple(x.shape), bias is not None
+        ctx.set_materialize_grads(False)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if dlogits is None:
+            return None, None, None
+        weight, pooled = ctx.saved_tensors
+        dx, dw, db = kernels.pooled_linear_bwd(dlogits.contiguous(), weight, pooled, ctx.x_shape, ctx.with_bias)
+        return dx, dw, db
+
+
+OWN_HEAD = os.environ.get('DEEPIPR_OWN_HEAD', '1') != '0'
+
+
+def pooled_linear(linear, x):
+    """linear(adaptive_avg_pool2d(x, 1).flatten(1)) -- the classifier of the reference's ResNets (models/resnet_passport.py:127-129
+    there: F.avg_pool2d(out, 4) on the 4x4 map, view, self.linear).  A plain nn.Linear nobody hooked, outside autocast, on a shape
+    the kernel takes (at most 128 classes, HW a multiple of 4: the CIFAR-geometry heads) goes through one launch per direction;
+    anything else -- the 1000-class ImageNet heads among them -- through the library ops.  DEEPIPR_OWN_HEAD=0: always the library."""
+    if (OWN_HEAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(linear) is torch.nn.Linear
+            and 'forward' not in linear.__dict__ and linear.weight.dtype == torch.float32
+            and not (linear._forward_hooks or linear._forward_pre_hooks or linear._backward_hooks or linear._backward_pre_hooks)
+            and not (_GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS or _GLOBAL_BWD_HOOKS or _GLOBAL_BWD_PRE_HOOKS)
+            and not torch.is_autocast_enabled() and linear.in_features == x.shape[1]
+            and kernels.pooled_linear_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], linear.out_features)):
+        return _PooledLinear.apply(x, linear.weight, linear.bias)
+    out = torch.nn.functional.adaptive_avg_pool2d(x, (1, 1))
+    return linear(out.view(out.size(0), -1))
 
 
 def cross_entropy_top1(pred, target):

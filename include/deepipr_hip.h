@@ -31,7 +31,7 @@ extern "C" {
 #define DEEPIPR_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define DEEPIPR_EUNSUPPORTED (-3)  /* shape outside the fused form (nothing was enqueued): use the unfused entry points */
 
-#define DEEPIPR_ABI_VERSION 11
+#define DEEPIPR_ABI_VERSION 12
 
 int deepipr_abi_version(void);
 const char *deepipr_last_error(void);
@@ -94,7 +94,8 @@ int deepipr_event_synchronize(void *event);
 #define DEEPIPR_K_RESAMPLE2 33            /* the stride-2 pixel gather / zero-interleaving scatter around a 1x1 stride-2 convolution (bytes) */
 #define DEEPIPR_K_CONV1X1_FWD 34          /* 1x1 stride-1 forward / backward-data GEMM over NCHW (deepipr_conv_1x1.inc): FLOPs */
 #define DEEPIPR_K_CONV1X1_DGRAD 35
-#define DEEPIPR_PROFILE_KERNELS 36
+#define DEEPIPR_K_HEAD 36                 /* avg-pool + Linear of the CIFAR-geometry classifier, forward / backward (bytes) */
+#define DEEPIPR_PROFILE_KERNELS 37
 int deepipr_profile_enable(int on);   /* 1 = reset counters and enable, 2 = resume without reset, 0 = pause */
 int deepipr_profile_read(int kernel, double *total_ms, long long *launches);
 /* algorithmic HBM bytes of the launches timed so far, for the streaming kernels (0 for the others) */
@@ -414,6 +415,21 @@ int deepipr_ce_top1_fwd(const float *logits, const long long *target, int N, int
                         float *lse, void *workspace, void *stream);
 int deepipr_ce_bwd(const float *dloss, const float *logits, const long long *target, const float *lse, int N, int C,
                    float *dlogits, void *stream);
+
+/* ------------------------------------------------------------------ the classifier of the CIFAR-geometry nets (ABI v12)
+ * logits[n][k] = b[k] + sum_c W[k][c] * mean_{hw} x[n][c][hw]        -- avg-pool to 1x1, flatten, nn.Linear -- in one launch,
+ * and its backward in one: dx[n][c][hw] = (sum_k dlogits[n][k] W[k][c]) / HW, dW[k][c] = sum_n dlogits[n][k] pooled[n][c],
+ * db[k] = sum_n dlogits[n][k].  `pooled` [N][C] is written by the forward and read by the backward.  fp32 sums in a fixed
+ * order: bit-reproducible.  b / db may be null (a Linear without bias).
+ * Supported (deepipr_pooled_linear_supported): C a multiple of 64 up to 4096, HW a multiple of 4 up to 256, K <= 128 classes;
+ * anything else (the ImageNet heads: 1000 classes, 7x7 maps) returns DEEPIPR_EUNSUPPORTED without enqueuing anything.
+ * replaces: F.avg_pool2d(out, 4) + view + self.linear(out) and their backward (models/resnet_passport.py:127-129 of the
+ *           reference): a mean reduce, three BLAS GEMMs, a broadcast-divide and a bias reduce -- 65 us of launch latency around 4 MB. */
+int deepipr_pooled_linear_supported(int N, int C, int HW, int K);
+int deepipr_pooled_linear_fwd(const float *x, const float *W, const float *b, float *pooled, float *logits, int N, int C, int HW,
+                              int K, void *stream);
+int deepipr_pooled_linear_bwd(const float *dlogits, const float *W, const float *pooled, float *dx, float *dW, float *db, int N,
+                              int C, int HW, int K, void *stream);
 
 /* The scalar bookkeeping of a train step in one launch (ABI v10): out[0] = terms[0] + ... + terms[n_a-1], out[1] = the sum of the
  * next n_b terms (both left to right -- the chain of one-element aten::add launches it replaces, bit for bit), out[2] = out[0] +

@@ -643,7 +643,7 @@ def test_stacked_branches_equal_one_pass_per_branch(K, case, monkeypatch):
     assert a['convs'] < b['convs'], (a['convs'], b['convs'])              # the stack really convolves once per layer
     assert np.allclose(a['outs'], b['outs'], rtol=1e-5, atol=1e-5), (a['outs'], b['outs'])
     assert np.allclose(a['sign'], b['sign'], rtol=1e-6, atol=1e-7)
-    worst = (0.0, None)
+    worst = (0.0, '')
     for k, v in b['state'].items():
         if k.endswith('num_batches_tracked'):
             assert int(a['state'][k]) == int(v), k
@@ -817,7 +817,7 @@ def test_resnet18_imagenet_geometry_at_batch_64_takes_the_channel_range_passes()
     assert float((out_p.detach().double() - out_r.detach()).abs().max()) <= 1e-4 * scale
     assert abs(float(sp) - float(sr)) <= 1e-4 * max(1.0, abs(float(sr)))
     gp = dict(prod.named_parameters())
-    worst = (0.0, None)
+    worst = (0.0, '')
     for name, p in ref.named_parameters():
         d = gp[name].grad.double() - p.grad
         rel = float(d.norm() / (p.grad.norm() + 1e-30))
