@@ -2796,16 +2796,34 @@ __global__ __launch_bounds__(kThreads) void k_pooled_linear_fwd(const float *__r
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float inv = 1.0f / static_cast<float>(HW);
     const float *xn = x + static_cast<size_t>(n) * C * HW;
-    for (int c = t; c < C; c += kThreads) {
-        const float4 *row = reinterpret_cast<const float4 *>(xn + static_cast<size_t>(c) * HW);
-        float s = 0.0f;
-        for (int q = 0; q < HW / 4; ++q) {
-            const float4 v = row[q];
-            s += (v.x + v.y) + (v.z + v.w);
+    const int q4 = HW / 4;
+    if (q4 <= 16 && (q4 & (q4 - 1)) == 0) {
+        // consecutive lanes read consecutive float4 of the image (whole cache lines per wavefront); the q4 lanes of a channel
+        // meet in a butterfly (fixed order)
+        const float4 *x4 = reinterpret_cast<const float4 *>(xn);
+        for (int i = t; i < C * q4; i += kThreads) {               // C * q4 is a multiple of the wavefront: no lane drops out
+            const float4 v = x4[i];
+            float s = (v.x + v.y) + (v.z + v.w);
+            for (int off = q4 >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+            if ((i & (q4 - 1)) == 0) {
+                const int c = i / q4;
+                s *= inv;
+                mean_s[c] = s;
+                if (kb == 0) pooled[static_cast<size_t>(n) * C + c] = s;
+            }
         }
-        s *= inv;
-        mean_s[c] = s;
-        if (kb == 0) pooled[static_cast<size_t>(n) * C + c] = s;
+    } else {
+        for (int c = t; c < C; c += kThreads) {
+            const float4 *row = reinterpret_cast<const float4 *>(xn + static_cast<size_t>(c) * HW);
+            float s = 0.0f;
+            for (int q = 0; q < q4; ++q) {
+                const float4 v = row[q];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            s *= inv;
+            mean_s[c] = s;
+            if (kb == 0) pooled[static_cast<size_t>(n) * C + c] = s;
+        }
     }
     __syncthreads();
     for (int k = kb * 8 + wave; k < min(K, kb * 8 + 8); k += kThreads / kWave) {
@@ -2830,12 +2848,20 @@ __global__ __launch_bounds__(kThreads) void k_pooled_linear_bwd(const float *__r
         float *dls = sh;
         for (int k = t; k < K; k += kThreads) dls[k] = dl[static_cast<size_t>(n) * K + k];
         __syncthreads();
-        if (c >= C) return;
         float g = 0.0f;
-        for (int k = 0; k < K; ++k) g = fmaf(dls[k], W[static_cast<size_t>(k) * C + c], g);       // coalesced over the channels
-        g *= 1.0f / static_cast<float>(HW);
-        float4 *o = reinterpret_cast<float4 *>(dx + (static_cast<size_t>(n) * C + c) * HW);
-        for (int q = 0; q < HW / 4; ++q) o[q] = make_float4(g, g, g, g);
+        if (c < C) {
+            for (int k = 0; k < K; ++k) g = fmaf(dls[k], W[static_cast<size_t>(k) * C + c], g);   // coalesced over the channels
+            g *= 1.0f / static_cast<float>(HW);
+        }
+        float *gs = sh + kHeadMaxK;                                // the slab's 256 channel gradients, then whole cache lines out
+        gs[t] = g;
+        __syncthreads();
+        const int q4 = HW / 4, c0 = (blockIdx.x - n * slabs) * kThreads, live = min(kThreads, C - c0) * q4;
+        float4 *o = reinterpret_cast<float4 *>(dx + (static_cast<size_t>(n) * C + c0) * HW);
+        for (int i = t; i < live; i += kThreads) {
+            const float v = gs[i / q4];
+            o[i] = make_float4(v, v, v, v);
+        }
         return;
     }
     // dW[k0 .. k0 + 7][c0 .. c0 + 63]: thread = (channel lane, image group g of four); group g sums images g, g + 4, ... in order
@@ -2844,6 +2870,7 @@ __global__ __launch_bounds__(kThreads) void k_pooled_linear_bwd(const float *__r
     float acc[8], accb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = accb[e] = 0.0f;
+#pragma unroll 4
     for (int n = g; n < N; n += 4) {
         const float pv = pooled[static_cast<size_t>(n) * C + c];
 #pragma unroll
