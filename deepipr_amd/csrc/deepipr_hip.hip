@@ -4797,7 +4797,7 @@ int deepipr_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Ci
         ProfScope prof(DEEPIPR_K_CONV_WINO_WGRAD, st);
         prof.bytes = 2.0 * Co * Ci * 16.0 * static_cast<double>(N) * ((H + 1) / 2) * ((W + 1) / 2);          // EXECUTED FLOPs (direct: x 2.25)
         const bool timed = prof.a && !prof.used;
-        if (!dipr_launch_wgrad_wino(p.cfg - 5000, x, dy, part, N, Ci, Co, H, p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split,
+        if (!dipr_launch_wgrad_wino(p.cfg - 5000 + (p.pairs ? 10000 : 0), x, dy, part, N, Ci, Co, H, p.tiles_co, p.tiles_ci, p.chunks, p.chunks_per_split,
                                     grid, st, timed ? prof.a : nullptr, timed ? prof.b : nullptr))
             return fail(DEEPIPR_EUNSUPPORTED, "conv_wgrad: no instance");
         if (timed) prof.used = true;

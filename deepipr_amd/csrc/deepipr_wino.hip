@@ -56,6 +56,24 @@ bool dispatch(const FwPlan &p, const float *wgt, const float *in, float *out, in
 
 bool dipr_launch_wgrad_wino(int width, const float *x, const float *dy, float *part, int N, int Ci, int Co, int H, int tiles_co,
                             int tiles_ci, int chunks, int chunks_per_split, int grid, hipStream_t st, hipEvent_t a, hipEvent_t b) {
+    if (width >= 10000) {                                       // two K ranges per workgroup (k_conv_wino_wgrad2): width + 10000
+#define DIPR_WW2(WW, TBR, NIB)                                                                                         \
+    do {                                                                                                              \
+        if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad2<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(512), 0, st, a, b, 0, x, dy, part, N, \
+                                     Ci, Co, H, tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());      \
+        else hipLaunchKernelGGL((k_conv_wino_wgrad2<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(512), 0, st, x, dy, part, N, Ci, Co, H,  \
+                                tiles_co, tiles_ci, chunks, chunks_per_split, dipr_xcd_remap());                      \
+        return true;                                                                                                  \
+    } while (0)
+        switch (width - 10000) {
+            case 32: DIPR_WW2(32, 1, 1);
+            case 16: DIPR_WW2(16, 2, 1);
+            case 8: DIPR_WW2(8, 4, 1);
+            case 4: DIPR_WW2(4, 2, 4);
+            default: return false;
+        }
+#undef DIPR_WW2
+    }
 #define DIPR_WW(WW, TBR, NIB)                                                                                          \
     do {                                                                                                              \
         if (a) hipExtLaunchKernelGGL((k_conv_wino_wgrad<WwCfg<WW, TBR, NIB>>), dim3(grid), dim3(256), 0, st, a, b, 0, x, dy, part, N, \

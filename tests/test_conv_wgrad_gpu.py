@@ -86,6 +86,36 @@ def test_wgrad_matches_the_float64_oracle_and_is_bit_reproducible(K, shape):
     assert torch.equal(got, again)
 
 
+def test_two_k_ranges_per_workgroup_agree_with_one(tmp_path):
+    """k_conv_wino_wgrad2 runs two K ranges in one eight-wavefront workgroup and leaves ONE partial tile per pair (half the bytes
+    for k_conv_wgrad_reduce); the planner takes it for short ranges only (<= 4 chunks: it measured slower on config R).  Forced on
+    (DEEPIPR_WGRAD_PAIR=2) and off (=0), a process each: both within 1e-5 of scale of float64 ATen, exact on small integers,
+    bit-reproducible; the forced runs ask for half the workspace and agree with the plain ones to rounding (a different
+    association of the same sum)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for mode in ('2', '0'):
+        out = str(tmp_path / ('pair%s.npz' % mode))
+        subprocess.run([sys.executable, os.path.join(here, 'wgrad_pair_case.py'), out], check=True, timeout=600,
+                       env=dict(os.environ, DEEPIPR_WGRAD_PAIR=mode, DEEPIPR_CONV_ALGO='winograd'))
+        got[mode] = np.load(out)
+    from tests.wgrad_pair_case import SHAPES
+    halved = 0
+    for i in range(len(SHAPES)):
+        for mode in ('2', '0'):
+            d = got[mode]
+            assert float(d['err_%d' % i]) <= 1e-5 and bool(d['repeat_%d' % i]) and bool(d['exact_%d' % i]), (SHAPES[i], mode)
+        a, b = int(got['2']['ws_%d' % i]), int(got['0']['ws_%d' % i])
+        assert 0 < a <= b
+        halved += int(2 * a <= b + b // 8)
+        x, y = got['2']['dw_%d' % i], got['0']['dw_%d' % i]
+        assert np.abs(x - y).max() <= 2e-6 * np.abs(y).max()
+    assert halved >= len(SHAPES) - 2                           # (a single K range has nothing to pair)
+
+
 @pytest.mark.parametrize('n,h', [(5, 224), (3, 64), (1, 8), (2, 226)])
 def test_imagenet_stem_wgrad_matches_the_float64_oracle(n, h):
     """k_conv_stem7_wgrad (deepipr_conv_stem7.inc): the weight gradient of Conv 3 -> 64, 7x7, stride 2, pad 3 on 224-wide images
