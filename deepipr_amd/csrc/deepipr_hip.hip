@@ -5011,6 +5011,18 @@ int conv_dgrad_s2(const float *dy, const float *w, float *dx, int N, int Ci, int
     prof.bytes = 2.0 * Ci * Co * k * k * static_cast<double>(N) * oh * ow;       // FLOPs
 #define DEEPIPR_DGRAD_X4(...)                                                                                         \
     DEEPIPR_LAUNCH(prof, (k_conv_dgrad_s2x4<FwCfg<__VA_ARGS__>>), dim3(p.grid), dim3(256), st, w, dy, dx, Co, Ci, oh, p.bands)
+    // chunks of 16 channels (round 6): a chunk of 8 is 18-36 MFMAs per wavefront between two barriers -- the barrier and the operand
+    // latencies behind it cost as much as the MFMAs; 16 halves the barriers per MFMA at one workgroup per CU (config R: the family
+    // 282 -> 246 us per step).  DEEPIPR_DGRAD_S2_CK16=0: the 8-channel instances (measurement)
+    static const int ck16 = getenv("DEEPIPR_DGRAD_S2_CK16") ? atoi(getenv("DEEPIPR_DGRAD_S2_CK16")) : 1;
+    if (ck16 && Co % 16 == 0) {
+        switch (p.cfg) {
+            case 11: DEEPIPR_DGRAD_X4(1, 9, 16, 8, 1, 4, 1, 16, 32); return check_launch("conv_dgrad");
+            case 41: DEEPIPR_DGRAD_X4(1, 9, 8, 8, 1, 2, 2, 16, 32); return check_launch("conv_dgrad");
+            case 61: DEEPIPR_DGRAD_X4(1, 9, 4, 4, 2, 1, 4, 16, 32); return check_launch("conv_dgrad");
+            default: break;
+        }
+    }
     switch (p.cfg) {                                               // W, RB, NIB, POSW, KG, CK, 32 positions per wave
         case 11: DEEPIPR_DGRAD_X4(1, 9, 16, 8, 1, 4, 1, 8, 32); break;      // 128 positions per workgroup
         case 21: DEEPIPR_DGRAD_X4(1, 9, 16, 4, 1, 2, 2, 8, 32); break;      // 64
