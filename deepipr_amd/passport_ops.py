@@ -1060,6 +1060,10 @@ WINO_PRE_MAX_FILTERS = int(os.environ.get('DEEPIPR_WINO_PRE_MAX_FILTERS', 1 << 3
 # convolution launches only when they are long enough (measured, bench.py replay: config R 128 images -1.5 %, V3 66 + 66
 # stacked -9.6 %, AlexNet 64 -4.6 %; config-P shard 32 images +1.6 %: off)
 WINO_PRE_MIN_BATCH = int(os.environ.get('DEEPIPR_WINO_PRE_MIN_BATCH', 48))
+# ... below it only the SMALL weights (at most this many filters: layer1 / layer2 of ResNet18, 0.9 MB of images): their
+# convolutions run the most workgroups per filter -- every one of them transforming the same 64 x 64 or 128 x 128 filters -- and
+# their transform launch is short (config-P shard, 32 images: 1.859 -> 1.837 ms; with layer3 too 1.841, with none 1.859)
+WINO_PRE_SMALL_FILTERS = int(os.environ.get('DEEPIPR_WINO_PRE_SMALL_FILTERS', 16384))
 
 
 _OWN_CONV_FROM_ENV = 'DEEPIPR_OWN_CONV' in os.environ
@@ -1742,8 +1746,11 @@ class wino_weights:
 
     def __init__(self, model, x):
         self.model = model
-        self.on = (torch.is_tensor(x) and bool(x.is_cuda) and WINO_PRE and x.shape[0] >= WINO_PRE_MIN_BATCH
-                   and kernels.conv_algo_is_winograd())
+        self.on = torch.is_tensor(x) and bool(x.is_cuda) and WINO_PRE and kernels.conv_algo_is_winograd()
+        self.max_filters = 0
+        if self.on:
+            self.max_filters = WINO_PRE_MAX_FILTERS if x.shape[0] >= WINO_PRE_MIN_BATCH else min(WINO_PRE_MAX_FILTERS, WINO_PRE_SMALL_FILTERS)
+            self.on = self.max_filters > 0
 
     def _convs(self):
         # the list is kept per model and rebuilt when the model's module set changed (model surgery after a first forward:
@@ -1764,7 +1771,7 @@ class wino_weights:
         if not self.on or self.before is not None:          # (a nested forward keeps the outer table)
             return self
         ws = [m.weight for m in self._convs() if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
-              and 0 < WINO_PRE_MAX_FILTERS >= m.weight.shape[0] * m.weight.shape[1]]
+              and self.max_filters >= m.weight.shape[0] * m.weight.shape[1]]
         if ws:
             backward = torch.is_grad_enabled()           # (the backward-data images only when a backward pass can follow)
             with torch.no_grad():
