@@ -67,6 +67,8 @@ SIGNATURES = {
     'deepipr_upsample2_zero': (_int, [_f32p, _f32p, _sz, _int, _int, _vp]),
     'deepipr_maxpool3x3s2_fwd': (_int, [_f32p, _f32p, _vp, _sz, _int, _int, _vp]),
     'deepipr_maxpool3x3s2_bwd': (_int, [_f32p, _vp, _f32p, _sz, _int, _int, _vp]),
+    'deepipr_maxpool2x2s2_fwd': (_int, [_f32p, _f32p, _vp, _sz, _int, _int, _vp]),
+    'deepipr_maxpool2x2s2_bwd': (_int, [_f32p, _vp, _f32p, _sz, _int, _int, _vp]),
     'deepipr_sgd_momentum_step': (_int, [_f32p, _f32p, _f32p, _sz, _flt, _flt, _flt, _flt, _vp]),
     'deepipr_sgd_momentum_step_dev': (_int, [_f32p, _f32p, _f32p, _sz, _f32p, _vp]),
     'deepipr_sgd_momentum_chunk': (_int, []),

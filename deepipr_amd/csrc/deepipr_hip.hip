@@ -4556,6 +4556,46 @@ __global__ __launch_bounds__(256) void k_maxpool3x3s2_bwd(const float *__restric
         dx[plane * H * W + i] = pool_gather(dp, sp, i / W, i % W, OH, OW);
     }
 }
+// 2x2 / 2: one thread per PAIR of windows (input columns 4 q .. 4 q + 3 of rows 2 oh, 2 oh + 1)
+__global__ __launch_bounds__(256) void k_maxpool2x2s2_fwd(const float *__restrict__ x, float *__restrict__ y,
+                                                          unsigned char *__restrict__ slot, size_t planes, int H, int W) {
+    const size_t plane = pool_plane();
+    if (plane >= planes) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, OH = H / 2, OW = W / 2, OW2 = W / 4;
+    if (i >= OH * OW2) return;
+    const int q = i % OW2, oh = i / OW2;
+    const float *xp = x + plane * H * W + (2 * oh) * W + 4 * q;
+    const float4 r0 = *reinterpret_cast<const float4 *>(xp), r1 = *reinterpret_cast<const float4 *>(xp + W);
+    float b0 = -INFINITY, b1 = -INFINITY;
+    int s0 = 0, s1 = 0;
+    pool_take(r0.x, 0, b0, s0);
+    pool_take(r0.y, 1, b0, s0);
+    pool_take(r1.x, 2, b0, s0);
+    pool_take(r1.y, 3, b0, s0);
+    pool_take(r0.z, 0, b1, s1);
+    pool_take(r0.w, 1, b1, s1);
+    pool_take(r1.z, 2, b1, s1);
+    pool_take(r1.w, 3, b1, s1);
+    const size_t o = (plane * OH + oh) * OW + 2 * q;
+    *reinterpret_cast<float2 *>(y + o) = make_float2(b0, b1);
+    *reinterpret_cast<uchar2 *>(slot + o) = make_uchar2(static_cast<unsigned char>(s0), static_cast<unsigned char>(s1));
+}
+
+// one thread per float4 of dx: two windows' gradients, selected by their slots
+__global__ __launch_bounds__(256) void k_maxpool2x2s2_bwd(const float *__restrict__ dy, const unsigned char *__restrict__ slot,
+                                                          float *__restrict__ dx, size_t planes, int H, int W) {
+    const size_t plane = pool_plane();
+    if (plane >= planes) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, OW = W / 2, W4 = W / 4;
+    if (i >= H * W4) return;
+    const int q = i % W4, h = i / W4;
+    const size_t o = (plane * (H / 2) + h / 2) * OW + 2 * q;
+    const float2 d = *reinterpret_cast<const float2 *>(dy + o);
+    const uchar2 s = *reinterpret_cast<const uchar2 *>(slot + o);
+    const int base = 2 * (h & 1);
+    const float4 v = make_float4(s.x == base ? d.x : 0.f, s.x == base + 1 ? d.x : 0.f, s.y == base ? d.y : 0.f, s.y == base + 1 ? d.y : 0.f);
+    *reinterpret_cast<float4 *>(dx + (plane * H + h) * W + 4 * q) = v;
+}
 }  // namespace
 
 extern "C" {
@@ -4588,6 +4628,37 @@ int deepipr_maxpool3x3s2_bwd(const float *dy, const unsigned char *slot, float *
     if (v4) DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_bwd<true>, grid, dim3(256), st, dy, slot, dx, planes, H, W, OH, OW);
     else DEEPIPR_LAUNCH(prof, k_maxpool3x3s2_bwd<false>, grid, dim3(256), st, dy, slot, dx, planes, H, W, OH, OW);
     return check_launch("maxpool3x3s2_bwd");
+}
+
+// ---- 2x2 stride-2 max-pool (the CIFAR AlexNet's pools, models/alexnet_passport.py:30-38 of the reference: nn.MaxPool2d(2, 2)):
+// non-overlapping windows, so the backward is a select -- dx = dy where the window's slot (0 .. 3, row-major, one byte) names
+// this pixel, else 0 -- bit for bit ATen's.  Even H, W a multiple of 4 (two windows per thread, one float4 per input row).
+int deepipr_maxpool2x2s2_fwd(const float *x, float *y, unsigned char *slot, size_t planes, int H, int W, void *stream) {
+    if (!x || !y || !slot || planes == 0 || H <= 0 || W <= 0) return fail(DEEPIPR_EINVAL, "maxpool2x2s2_fwd: bad argument");
+    if (H % 2 || W % 4 || !aligned16(x) || (reinterpret_cast<uintptr_t>(y) & 7u) || (reinterpret_cast<uintptr_t>(slot) & 1u))
+        return fail(DEEPIPR_EUNSUPPORTED, "maxpool2x2s2_fwd: even H, W a multiple of 4, aligned pointers (use the library's pool)");
+    if (static_cast<long long>(H) * W >= (1ll << 30) || planes >= 65535ull * 65535ull) return fail(DEEPIPR_EINVAL, "maxpool2x2s2_fwd: tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_MAXPOOL, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * H * W + 5.0 * static_cast<double>(planes) * (H / 2) * (W / 2);
+    const unsigned py = static_cast<unsigned>(planes < 65535 ? planes : 65535), pz = static_cast<unsigned>((planes + 65534) / 65535);
+    const dim3 grid(static_cast<unsigned>(((H / 2) * (W / 4) + 255) / 256), py, pz);
+    DEEPIPR_LAUNCH(prof, k_maxpool2x2s2_fwd, grid, dim3(256), st, x, y, slot, planes, H, W);
+    return check_launch("maxpool2x2s2_fwd");
+}
+
+int deepipr_maxpool2x2s2_bwd(const float *dy, const unsigned char *slot, float *dx, size_t planes, int H, int W, void *stream) {
+    if (!dy || !dx || !slot || planes == 0 || H <= 0 || W <= 0) return fail(DEEPIPR_EINVAL, "maxpool2x2s2_bwd: bad argument");
+    if (H % 2 || W % 4 || !aligned16(dx) || (reinterpret_cast<uintptr_t>(dy) & 7u) || (reinterpret_cast<uintptr_t>(slot) & 1u))
+        return fail(DEEPIPR_EUNSUPPORTED, "maxpool2x2s2_bwd: even H, W a multiple of 4, aligned pointers");
+    if (static_cast<long long>(H) * W >= (1ll << 30) || planes >= 65535ull * 65535ull) return fail(DEEPIPR_EINVAL, "maxpool2x2s2_bwd: tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DEEPIPR_K_MAXPOOL, st);
+    prof.bytes = 4.0 * static_cast<double>(planes) * H * W + 5.0 * static_cast<double>(planes) * (H / 2) * (W / 2);
+    const unsigned py = static_cast<unsigned>(planes < 65535 ? planes : 65535), pz = static_cast<unsigned>((planes + 65534) / 65535);
+    const dim3 grid(static_cast<unsigned>((H * (W / 4) + 255) / 256), py, pz);
+    DEEPIPR_LAUNCH(prof, k_maxpool2x2s2_bwd, grid, dim3(256), st, dy, slot, dx, planes, H, W);
+    return check_launch("maxpool2x2s2_bwd");
 }
 
 }  // extern "C"

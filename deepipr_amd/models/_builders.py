@@ -26,6 +26,9 @@ def run_layer(layer, x, force_passport, ind):
         return layer(x, force_passport, ind)
     if isinstance(layer, PassportBlock):
         return layer(x, force_passport)
+    if type(layer) is torch.nn.MaxPool2d:
+        from deepipr_amd.passport_ops import max_pool       # (passport_ops imports nothing from models: no cycle at call time)
+        return max_pool(layer, x)
     return layer(x)
 
 

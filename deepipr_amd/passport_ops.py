@@ -650,6 +650,24 @@ class HipKernels:
             _lib.check(_lib.lib().deepipr_maxpool3x3s2_bwd(_p(dy), slot.data_ptr(), _p(dx), n * c, h, w, _stream(dev)), 'maxpool3x3s2_bwd')
         return dx
 
+    def maxpool2x2s2_fwd(self, x):
+        """nn.MaxPool2d(2, 2)(x) -> (y, slot) for even H and W a multiple of 4 (deepipr_maxpool2x2s2_fwd)."""
+        dev = _chk(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=dev)
+        slot = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_maxpool2x2s2_fwd(_p(x), _p(y), slot.data_ptr(), n * c, h, w, _stream(dev)), 'maxpool2x2s2_fwd')
+        return y, slot
+
+    def maxpool2x2s2_bwd(self, dy, slot, x_shape):
+        dev = _chk(dy)
+        n, c, h, w = x_shape
+        dx = torch.empty(x_shape, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.check(_lib.lib().deepipr_maxpool2x2s2_bwd(_p(dy), slot.data_ptr(), _p(dx), n * c, h, w, _stream(dev)), 'maxpool2x2s2_bwd')
+        return dx
+
     def scalar_sums(self, terms, n_a):
         """-> 3 floats {sum of the first n_a single-element tensors, sum of the rest, both}: left-to-right fp32 adds in ONE launch
         (deepipr_scalar_sums) instead of len(terms) one-element aten::add launches."""
@@ -2035,18 +2053,44 @@ class _MaxPool3x3s2(torch.autograd.Function):
         return kernels.maxpool3x3s2_bwd(dy.contiguous(), slot, ctx.x_shape)
 
 
+OWN_POOL = os.environ.get('DEEPIPR_OWN_POOL', '1') != '0'      # 0: every max-pool through the library (A/B)
+
+
+class _MaxPool2x2s2(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) of the CIFAR AlexNet (models/alexnet_passport.py:30-38 of the reference): a one-byte argmax, the
+    backward a select (bit-identical to F.max_pool2d both ways)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y, slot = kernels.maxpool2x2s2_fwd(x)
+        ctx.save_for_backward(slot)
+        ctx.x_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        slot, = ctx.saved_tensors
+        return kernels.maxpool2x2s2_bwd(dy.contiguous(), slot, ctx.x_shape)
+
+
 def max_pool(pool, x):
-    """pool(x) for an nn.MaxPool2d: this library's kernel for the stem's 3x3 / 2 / pad 1 pool of a float32 CUDA map nobody
-    hooked, the module call otherwise."""
+    """pool(x) for an nn.MaxPool2d: this library's kernels for the ImageNet stem's 3x3 / 2 / pad 1 pool and the CIFAR AlexNet's
+    2x2 / 2 pools of a float32 CUDA map nobody hooked, the module call otherwise."""
     def two(v):
         return (v, v) if isinstance(v, int) else tuple(v)
-    if (type(pool) is torch.nn.MaxPool2d and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and two(pool.kernel_size) == (3, 3) and two(pool.stride) == (2, 2) and two(pool.padding) == (1, 1)
+    if (OWN_POOL and type(pool) is torch.nn.MaxPool2d and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and two(pool.stride if pool.stride is not None else pool.kernel_size) == (2, 2)
             and two(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices
             and not (pool._forward_hooks or pool._forward_pre_hooks or pool._backward_hooks or pool._backward_pre_hooks)
             and not (_GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS or _GLOBAL_BWD_HOOKS or _GLOBAL_BWD_PRE_HOOKS)
             and not torch.is_autocast_enabled() and 'forward' not in pool.__dict__):
-        return _MaxPool3x3s2.apply(x)
+        if two(pool.kernel_size) == (3, 3) and two(pool.padding) == (1, 1):
+            return _MaxPool3x3s2.apply(x)
+        # the CIFAR AlexNet's 2x2 / 2 pools: even maps whose width is a multiple of 4 (32 / 16 / 8 wide)
+        if (two(pool.kernel_size) == (2, 2) and two(pool.padding) == (0, 0) and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0
+                and x.numel() > 0):
+            return _MaxPool2x2s2.apply(x)
     return pool(x)
 
 
@@ -2150,6 +2194,7 @@ def pooled_linear(linear, x):
         return _PooledLinear.apply(x, linear.weight, linear.bias)
     out = torch.nn.functional.adaptive_avg_pool2d(x, (1, 1))
     return linear(out.view(out.size(0), -1))
+
 
 
 def cross_entropy_top1(pred, target):

@@ -457,6 +457,11 @@ int deepipr_relu_bwd2(const float *dy, const float *dy2, const float *out, float
  * replaces: nn.MaxPool2d(3, 2, 1) and its backward, models/resnet_passport.py:94-98 (the 224 x 224 stem). */
 int deepipr_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *slot, size_t planes, int H, int W, void *stream);
 int deepipr_maxpool3x3s2_bwd(const float *dy, const unsigned char *slot, float *dx, size_t planes, int H, int W, void *stream);
+/* 2x2 stride-2 pad-0 max-pool (the CIFAR AlexNet's nn.MaxPool2d(2, 2), models/alexnet_passport.py:30-38; ABI v12): the same
+ * contract with window slots 0 .. 3; even H, W a multiple of 4 -- anything else returns DEEPIPR_EUNSUPPORTED (keep the library's).
+ * x, dx [planes][H][W]; y, dy, slot [planes][H/2][W/2].  Bit-identical to ATen's forward values and backward. */
+int deepipr_maxpool2x2s2_fwd(const float *x, float *y, unsigned char *slot, size_t planes, int H, int W, void *stream);
+int deepipr_maxpool2x2s2_bwd(const float *dy, const unsigned char *slot, float *dx, size_t planes, int H, int W, void *stream);
 
 /* ------------------------------------------------------------------ 1x1 stride-2 convolution = pixel gather + stride-1 GEMM
  * deepipr_subsample2: y[plane][oh][ow] = x[plane][2 oh][2 ow] (H, W even; planes = N * C).  deepipr_upsample2_zero: its adjoint,
